@@ -1,0 +1,380 @@
+"""CPU restatement (pure PyTorch, fp32) of the reference's neural-process hot path.
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  This file is the checker the
+HIP path is compared against and the ``cpu_baseline`` timed by ``bench.py``; the product
+never imports it.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference
+(``/root/reference/npf``) in the build container, runs it on seeded inputs and stores the
+results under ``tests/golden/*.npz``; ``tests/test_oracle.py`` requires this restatement
+to reproduce them bit-for-bit on the small cases (G1/G2/G6/G7) and within the stated
+fp32 tolerance on the large ones (G3-G5; the last-ulp level there depends on the BLAS
+blocking).
+
+Style: functional and state_dict driven -- every function takes the flat parameter
+dict (reference key names, e.g. ``decoder.flat_module.linears.0.weight``) so that the
+same dict drives the reference, this oracle and the HIP path.  Every function cites the
+reference lines it restates (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+MODEL_KINDS = ("CNP", "LNP", "AttnCNP", "AttnLNP")
+
+
+@dataclass
+class OracleConfig:
+    """What the reference's constructors fix (npf/neuralproc/base.py:104-152,423-460;
+    np.py:54,141; attnnp.py:66-101,161-162).  Layer sizes are NOT listed here: they are
+    read off the parameter dict."""
+
+    kind: str
+    x_dim: int = 1
+    y_dim: int = 2
+    r_dim: int = 128
+    encoded_path: Optional[str] = None  # default per kind, as the reference classes force it
+    is_heteroskedastic: bool = True
+    is_q_zCct: bool = False
+    z_dim: Optional[int] = None
+
+    def __post_init__(self):
+        if self.kind not in MODEL_KINDS:
+            raise ValueError(f"unknown kind {self.kind}")
+        if self.encoded_path is None:
+            self.encoded_path = {
+                "CNP": "deterministic",
+                "AttnCNP": "deterministic",
+                "LNP": "latent",
+                "AttnLNP": "both",
+            }[self.kind]
+        if self.z_dim is None:
+            self.z_dim = self.r_dim
+
+    @property
+    def is_latent(self) -> bool:
+        return self.kind in ("LNP", "AttnLNP")
+
+    @property
+    def is_attentive(self) -> bool:
+        return self.kind in ("AttnCNP", "AttnLNP")
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def mlp(params: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU, no dropout, no
+    residual: to_hidden -> relu -> [linears.i -> relu]* -> out (no activation)."""
+    h = torch.relu(F.linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
+    i = 0
+    while f"{prefix}.linears.{i}.weight" in params:
+        h = torch.relu(F.linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
+        i += 1
+    return F.linear(h, params[f"{prefix}.out.weight"], params[f"{prefix}.out.bias"])
+
+
+def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """``MergeFlatInputs.forward`` with ``is_sum_merge=True``
+    (npf/architectures/encoders.py:175-183): flat(relu(x1 + resizer(x2)))."""
+    x2 = mlp(params, f"{prefix}.resizer", x2)
+    return mlp(params, f"{prefix}.flat_module", torch.relu(x1 + x2))
+
+
+def scaledot_attend(keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+    """``get_attender("scaledot")`` = ``DotAttender`` on ``BaseAttender.forward``
+    (npf/architectures/attention.py:129-164,204-220): softmax(Q K^T / sqrt(d)) V, single
+    head, no learned projections, no resizer (value_size == out_size on this path)."""
+    logits = torch.einsum("bkd,bqd->bqk", keys, queries) / math.sqrt(queries.size(-1))
+    attn = logits.softmax(dim=-1)
+    return torch.bmm(attn, values)
+
+
+def p_y_scale_transform(raw: torch.Tensor) -> torch.Tensor:
+    """npf/neuralproc/base.py:116."""
+    return 0.01 + 0.99 * F.softplus(raw)
+
+
+def q_z_scale_transform(raw: torch.Tensor) -> torch.Tensor:
+    """npf/neuralproc/base.py:432."""
+    return 0.1 + 0.9 * torch.sigmoid(raw)
+
+
+# --------------------------------------------------------------------------------------
+# model stages (same split as the reference's public methods)
+# --------------------------------------------------------------------------------------
+def encode_globally(cfg: OracleConfig, params: Params, X_enc: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """``CNP.encode_globally`` (npf/neuralproc/np.py:86-101): per-point XY encoding then
+    mean over the context points; ``AttnCNP.encode_globally``
+    (npf/neuralproc/attnnp.py:105-116): per-point XY encoding, no pooling."""
+    B, C, _ = X_enc.shape
+    if cfg.is_attentive:
+        if C == 0:
+            return torch.zeros(B, 0, cfg.r_dim)
+        return merge_flat_sum(params, "xy_encoder", X_enc, Y)
+    R_cntxt = merge_flat_sum(params, "xy_encoder", X_enc, Y)
+    R = torch.mean(R_cntxt, dim=1, keepdim=True)
+    if C == 0:
+        R = torch.zeros(B, 1, cfg.r_dim)
+    return R
+
+
+def rep_to_lat_input(cfg: OracleConfig, R: torch.Tensor) -> torch.Tensor:
+    """Identity for LNP (npf/neuralproc/base.py:549-552); mean over context for AttnLNP
+    (npf/neuralproc/attnnp.py:172-181)."""
+    if not cfg.is_attentive:
+        return R
+    B, C, _ = R.shape
+    if C == 0:
+        R = torch.zeros(B, 1, cfg.r_dim)
+    return torch.mean(R, dim=1, keepdim=True)
+
+
+def infer_latent_dist(cfg: OracleConfig, params: Params, R: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``infer_latent_dist`` (npf/neuralproc/base.py:516-547) -> (loc, scale) of the
+    diagonal Gaussian."""
+    suff = mlp(params, "latent_encoder", rep_to_lat_input(cfg, R))
+    loc, raw = suff.split(cfg.z_dim, dim=-1)
+    return loc, q_z_scale_transform(raw)
+
+
+def merge_r_z(cfg: OracleConfig, params: Params, R: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """``merge_r_z`` (npf/neuralproc/base.py:554-575)."""
+    if R.shape != z.shape:
+        R = R.unsqueeze(0).expand(*z.shape[:-1], cfg.r_dim)
+    return torch.relu(F.linear(torch.cat((R, z), dim=-1), params["r_z_merger.weight"], params["r_z_merger.bias"]))
+
+
+def trgt_dependent_representation(cfg, params, Xc_enc, z_samples, R, Xt_enc) -> torch.Tensor:
+    """np.py:103-110 (CNP), np.py:144-163 (LNP), attnnp.py:118-131 (AttnCNP),
+    attnnp.py:183-202 (AttnLNP).  Returns [n_z, B, T, r]."""
+    B, T, _ = Xt_enc.shape
+    if cfg.kind == "CNP":
+        return R.expand(B, T, cfg.r_dim).unsqueeze(0)
+    if cfg.kind == "LNP":
+        n_z = z_samples.size(0)
+        if cfg.encoded_path == "both":
+            R_trgt = merge_r_z(cfg, params, R, z_samples)
+        else:
+            R_trgt = z_samples
+            if cfg.z_dim != cfg.r_dim:
+                R_trgt = F.linear(R_trgt, params["reshaper_z.weight"], params["reshaper_z.bias"])
+        return R_trgt.expand(n_z, B, T, cfg.r_dim)
+    # attentive
+    if Xc_enc.shape[1] == 0:
+        R_det = torch.zeros(B, T, cfg.r_dim)
+    else:
+        R_det = scaledot_attend(Xc_enc, Xt_enc, R)
+    if cfg.kind == "AttnCNP":
+        return R_det.unsqueeze(0)
+    n_z = z_samples.size(0)
+    z = z_samples.expand(n_z, B, T, cfg.z_dim)
+    return merge_r_z(cfg, params, R_det, z)
+
+
+def decode(cfg: OracleConfig, params: Params, Xt_enc: torch.Tensor, R_trgt: torch.Tensor):
+    """``NeuralProcessFamily.decode`` (npf/neuralproc/base.py:327-367) -> (loc, scale),
+    each [n_z, B, T, y_dim]; homoskedastic pooling per
+    npf/neuralproc/helpers.py:21-32."""
+    suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt)
+    loc, raw = suff.split(cfg.y_dim, dim=-1)
+    scale = p_y_scale_transform(raw)
+    if not cfg.is_heteroskedastic:
+        n_z, B, T, dy = scale.shape
+        s = scale.view(n_z * B, T, dy).mean(1, keepdim=True)
+        scale = s.expand(n_z * B, T, dy).view(n_z, B, T, dy)
+    return loc, scale
+
+
+def forward(
+    cfg: OracleConfig,
+    params: Params,
+    X_cntxt: torch.Tensor,
+    Y_cntxt: torch.Tensor,
+    X_trgt: torch.Tensor,
+    Y_trgt: Optional[torch.Tensor] = None,
+    eps: Optional[torch.Tensor] = None,
+    n_z: int = 1,
+    training: bool = True,
+) -> dict:
+    """``NeuralProcessFamily.forward`` (npf/neuralproc/base.py:177-239) and the latent
+    path (base.py:475-514).  ``eps`` [n_z, B, 1, z] replaces the reference's global-RNG
+    draw inside ``rsample`` (base.py:512): z = loc + eps * scale.
+
+    Returns a dict with ``loc``/``scale`` [n_z,B,T,dy] and, for latent models,
+    ``z_samples`` and the (loc, scale) pairs ``q_zCc`` / ``q_zCct``.
+    """
+    if training:
+        # base.py:241-247 / npf/utils/helpers.py:55-57
+        ok = ((X_cntxt >= -1) & (X_cntxt <= 1)).all() and ((X_trgt >= -1) & (X_trgt <= 1)).all()
+        if not ok:
+            raise ValueError("Features during training should be in [-1,1].")
+    Xc_enc = mlp(params, "x_encoder", X_cntxt)
+    Xt_enc = mlp(params, "x_encoder", X_trgt)
+    R = encode_globally(cfg, params, Xc_enc, Y_cntxt)
+
+    out = {"z_samples": None, "q_zCc": None, "q_zCct": None}
+    z_samples = None
+    if cfg.is_latent:
+        q_zCc = infer_latent_dist(cfg, params, R)
+        if cfg.is_q_zCct and Y_trgt is not None:
+            R_from_trgt = encode_globally(cfg, params, Xt_enc, Y_trgt)
+            q_zCct = infer_latent_dist(cfg, params, R_from_trgt)
+            samp = q_zCct
+        else:
+            q_zCct = None
+            samp = q_zCc
+        if eps is None:
+            raise ValueError("latent models need an explicit eps (the reference draws it from torch's global RNG)")
+        assert eps.shape[0] == n_z
+        z_samples = samp[0] + eps * samp[1]
+        out.update(z_samples=z_samples, q_zCc=q_zCc, q_zCct=q_zCct)
+    if cfg.encoded_path == "latent":
+        R = None
+    R_trgt = trgt_dependent_representation(cfg, params, Xc_enc, z_samples, R, Xt_enc)
+    loc, scale = decode(cfg, params, Xt_enc, R_trgt)
+    out.update(loc=loc, scale=scale, Xc_enc=Xc_enc, Xt_enc=Xt_enc, R=R, R_trgt=R_trgt)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# losses (npf/losses.py)
+# --------------------------------------------------------------------------------------
+def _normal_log_prob(loc, scale, value):
+    """``torch.distributions.Normal.log_prob`` restated op-for-op (var, log, same
+    association) so that results are bit-identical to the reference's
+    ``Independent(Normal)`` (npf/utils/helpers.py:125-129)."""
+    var = scale ** 2
+    log_scale = scale.log()
+    return -((value - loc) ** 2) / (2 * var) - log_scale - math.log(math.sqrt(2 * math.pi))
+
+
+def sum_log_prob(loc, scale, value, batch_ndim: int = 2):
+    """``sum_log_prob`` (npf/losses.py:18-24) for ``Independent(Normal(loc, scale), 1)``:
+    sum over the event dim then over everything past the first two dims."""
+    lp = _normal_log_prob(loc, scale, value).sum(-1)
+    return lp.view(*lp.shape[:batch_ndim], -1).sum(-1)
+
+
+def _kl_normal(p_loc, p_scale, q_loc, q_scale):
+    """``kl_divergence(Normal p, Normal q)`` as torch/distributions/kl.py states it."""
+    var_ratio = (p_scale / q_scale).pow(2)
+    t1 = ((p_loc - q_loc) / q_scale).pow(2)
+    return 0.5 * (var_ratio + t1 - 1 - var_ratio.log())
+
+
+def cnpf_loss(out: dict, Y_trgt: torch.Tensor, reduction: Optional[str] = "mean"):
+    """``CNPFLoss`` (npf/losses.py:112-123) + batch reduction (losses.py:71-81)."""
+    assert out["q_zCc"] is None
+    nll = -sum_log_prob(out["loc"], out["scale"], Y_trgt).squeeze(0)
+    return _reduce(nll, reduction)
+
+
+def elbo_loss(out: dict, Y_trgt: torch.Tensor, reduction: Optional[str] = "mean"):
+    """``ELBOLossLNPF`` (npf/losses.py:126-150): needs q_zCct (is_q_zCct=True)."""
+    s = sum_log_prob(out["loc"], out["scale"], Y_trgt).mean(0)
+    kl = _kl_normal(*out["q_zCct"], *out["q_zCc"]).sum(-1)  # Independent: sum event dim
+    kl = kl.view(kl.shape[0], -1).sum(-1)
+    return _reduce(-(s - kl), reduction)
+
+
+def nll_loss(out: dict, Y_trgt: torch.Tensor, reduction: Optional[str] = "mean"):
+    """``NLLLossLNPF`` (npf/losses.py:153-203) incl. the importance weights when q_zCct
+    is present."""
+    s = sum_log_prob(out["loc"], out["scale"], Y_trgt)
+    n_z = s.shape[0]
+    if out["q_zCct"] is not None:
+        z = out["z_samples"]
+        s = s + sum_log_prob(*out["q_zCc"], z) - sum_log_prob(*out["q_zCct"], z)
+    return _reduce(-(torch.logsumexp(s, 0) - math.log(n_z)), reduction)
+
+
+def _reduce(loss, reduction):
+    if reduction is None:
+        return loss
+    if reduction == "mean":
+        return loss.mean(0)
+    if reduction == "sum":
+        return loss.sum(0)
+    raise ValueError(f"Unknown {reduction}")
+
+
+# --------------------------------------------------------------------------------------
+# parameter construction (reference initialisation)
+# --------------------------------------------------------------------------------------
+def mlp_shapes(prefix: str, n_in: int, n_out: int, hidden: int, n_hidden_layers: int, force_smaller=False):
+    """Layer shapes of ``MLP.__init__`` incl. the hidden-size clamp
+    (npf/architectures/mlp.py:64-79)."""
+    if force_smaller and hidden > max(n_out, n_in):
+        hidden = max(n_out, n_in)
+    elif hidden < min(n_out, n_in):
+        hidden = min(n_out, n_in)
+    shapes = [(f"{prefix}.to_hidden", hidden, n_in)]
+    for i in range(n_hidden_layers - 1):
+        shapes.append((f"{prefix}.linears.{i}", hidden, hidden))
+    shapes.append((f"{prefix}.out", n_out, hidden))
+    return shapes
+
+
+def model_shapes(cfg: OracleConfig, n_layers_xy: int = 2, n_layers_dec: int = 4):
+    """(name, out_features, in_features) for every Linear of the stock model, in the
+    reference's state_dict order (base.py:143-146,157-175; np.py:62-82; base.py:447-458)."""
+    r, dx, dy = cfg.r_dim, cfg.x_dim, cfg.y_dim
+    shapes = mlp_shapes("x_encoder", dx, r, r, 1)
+    shapes += mlp_shapes("decoder.resizer", r, r, 32, 1)
+    shapes += mlp_shapes("decoder.flat_module", r, 2 * dy, r, n_layers_dec)
+    shapes += mlp_shapes("xy_encoder.resizer", dy, r, 32, 1)
+    shapes += mlp_shapes("xy_encoder.flat_module", r, r, r, n_layers_xy, force_smaller=True)
+    if cfg.is_latent:
+        shapes += mlp_shapes("latent_encoder", r, 2 * cfg.z_dim, r, 1)
+        if cfg.encoded_path == "both":
+            shapes.append(("r_z_merger", r, r + cfg.z_dim))
+        if cfg.z_dim != r and cfg.encoded_path == "latent":
+            shapes.append(("reshaper_z", r, cfg.z_dim))
+    return shapes
+
+
+def init_params(cfg: OracleConfig, seed: int = 0, n_layers_xy: int = 2, n_layers_dec: int = 4) -> Params:
+    """Deterministic parameters with the reference's *effective* init statistics
+    (npf/utils/initialization.py:7-94, behaviour documented in SURVEY.md 8a row 12):
+    hidden Linear weights U(+-1/sqrt(fan_in)), ``.out`` weights U(+-sqrt(6/fan_in)), MLP
+    biases 0, ``r_z_merger``/``reshaper_z`` torch-default incl. non-zero bias.  The draw
+    itself is this project's own (numpy Philox stream), so the same dict can be
+    regenerated on the GPU box without the reference."""
+    import numpy as np
+
+    rng = np.random.Generator(np.random.Philox(seed))
+    params: Params = {}
+    for name, n_out, n_in in model_shapes(cfg, n_layers_xy, n_layers_dec):
+        if name.endswith(".out"):
+            bound = math.sqrt(6.0 / n_in)
+        else:
+            bound = 1.0 / math.sqrt(n_in)
+        w = rng.uniform(-bound, bound, size=(n_out, n_in)).astype("float32")
+        if name in ("r_z_merger", "reshaper_z"):
+            b = rng.uniform(-bound, bound, size=(n_out,)).astype("float32")
+        else:
+            b = np.zeros((n_out,), dtype="float32")
+        params[f"{name}.weight"] = torch.from_numpy(w)
+        params[f"{name}.bias"] = torch.from_numpy(b)
+    return params
+
+
+def perturb_biases(params: Params, seed: int = 1, scale: float = 0.05) -> Params:
+    """Non-zero biases for parity tests (the reference zero-inits them, which would hide
+    a bias-indexing bug)."""
+    import numpy as np
+
+    rng = np.random.Generator(np.random.Philox(seed))
+    out = dict(params)
+    for k, v in params.items():
+        if k.endswith(".bias"):
+            out[k] = torch.from_numpy(rng.uniform(-scale, scale, size=tuple(v.shape)).astype("float32"))
+    return out

@@ -1,0 +1,230 @@
+"""Generate the golden vectors by running the REFERENCE (``/root/reference/npf``).
+
+Runs in the build container only (the reference does not exist on the GPU box); the
+``.npz`` files it writes next to itself are committed.  Usage::
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What it does per case (see ``specs.CASES``): builds the reference model class with the
+reference's own factories, loads this project's seeded parameter dict into it
+(``load_state_dict(strict=True)`` -- which also proves the state_dict key contract),
+runs forward + loss + backward (+ one Adam step for G1) on the seeded inputs and stores
+inputs-independent results: loc, scale, latent stats, loss, gradients.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import specs  # noqa: E402
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore", category=UserWarning)
+
+import npf  # noqa: E402  (the reference)
+from npf.architectures import MLP, merge_flat_input  # noqa: E402
+from torch.distributions import Independent, Normal  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class _EpsIndependent(Independent):
+    """Independent(Normal) whose rsample uses an injected eps instead of the global RNG
+    (passed to the reference through its ``LatentDistribution`` constructor argument)."""
+
+    eps = None
+
+    def rsample(self, sample_shape=torch.Size()):
+        e = type(self).eps
+        assert e is not None and e.shape[0] == sample_shape[0]
+        return self.base_dist.loc + e * self.base_dist.scale
+
+
+def _latent_dist(loc, scale):
+    return _EpsIndependent(Normal(loc, scale), 1)
+
+
+def build_reference(case: dict):
+    r = case["r"]
+    kw = dict(
+        r_dim=r,
+        is_heteroskedastic=case.get("is_heteroskedastic", True),
+        XYEncoder=merge_flat_input(
+            partial(MLP, n_hidden_layers=case["L_xy"], is_force_hid_smaller=True, hidden_size=r), is_sum_merge=True
+        ),
+        Decoder=merge_flat_input(partial(MLP, n_hidden_layers=case["L_dec"], hidden_size=r), is_sum_merge=True),
+    )
+    kind = case["kind"]
+    if kind in ("LNP", "AttnLNP"):
+        n_z = case.get("n_z", 1)
+        kw.update(is_q_zCct=case.get("is_q_zCct", False), n_z_samples_train=n_z, n_z_samples_test=n_z,
+                  LatentDistribution=_latent_dist)
+    if kind == "CNP":
+        m = npf.CNP(case["dx"], case["dy"], **kw)
+    elif kind == "LNP":
+        m = npf.LNP(case["dx"], case["dy"], encoded_path=case["encoded_path"], **kw)
+    elif kind == "AttnCNP":
+        m = npf.AttnCNP(case["dx"], case["dy"], attention="scaledot", **kw)
+    else:
+        m = npf.AttnLNP(case["dx"], case["dy"], attention="scaledot", **kw)
+    return m
+
+
+def ref_loss(case: dict):
+    return {"cnpf": npf.CNPFLoss, "elbo": npf.ELBOLossLNPF, "nll": npf.NLLLossLNPF}[specs.loss_name(case)]()
+
+
+def run_case(name: str, case: dict, store_params: bool, store_full_grads: bool, adam_step: bool = False):
+    params = specs.make_params(case)
+    inp = specs.make_inputs(case)
+    model = build_reference(case)
+    missing = model.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.train()
+    if "eps" in inp:
+        _EpsIndependent.eps = inp["eps"]
+    crit = ref_loss(case)
+    crit.train()
+    out = model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+    p_yCc, z_samples, q_zCc, q_zCct = out
+    loss = crit(out, inp["Y_trgt"])
+    loss.backward()
+
+    res = {
+        "loc": p_yCc.base_dist.loc.detach().numpy(),
+        "scale": p_yCc.base_dist.scale.detach().numpy(),
+        "loss": loss.detach().numpy(),
+        "n_params": np.array(sum(p.numel() for p in model.parameters())),
+    }
+    if z_samples is not None:
+        res["z_samples"] = z_samples.detach().numpy()
+        res["q_zCc_loc"] = q_zCc.base_dist.loc.detach().numpy()
+        res["q_zCc_scale"] = q_zCc.base_dist.scale.detach().numpy()
+        if q_zCct is not None:
+            res["q_zCct_loc"] = q_zCct.base_dist.loc.detach().numpy()
+            res["q_zCct_scale"] = q_zCct.base_dist.scale.detach().numpy()
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        if store_full_grads:
+            res[f"grad/{k}"] = g.numpy().copy()
+        else:
+            res[f"gradnorm/{k}"] = np.array(g.double().norm().item())
+            res[f"gradhead/{k}"] = g.reshape(-1)[:64].numpy().copy()
+    if store_params:
+        for k, v in params.items():
+            res[f"param/{k}"] = v.numpy()
+    # eval-mode forward (losses.py:65-69 uses NLL for eval; n_z_samples_test)
+    model.eval()
+    with torch.no_grad():
+        out_e = model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"])
+    res["eval_loc"] = out_e[0].base_dist.loc.numpy()
+    res["eval_scale"] = out_e[0].base_dist.scale.numpy()
+    if adam_step:
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt.step()
+        for k, p in model.named_parameters():
+            res[f"adam1/{k}"] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **res)
+    print(f"{name}: loss={float(loss):.6f} n_params={int(res['n_params'])} keys={len(res)}")
+
+
+def run_decode_case():
+    case = specs.DECODE_CASE
+    cfg, dparams = specs.make_decode_params(case)
+    inp = specs.make_decode_inputs(case)
+    model = npf.CNP(case["dx"], case["dy"], r_dim=case["r"],
+                    Decoder=merge_flat_input(partial(MLP, n_hidden_layers=case["L_dec"], hidden_size=case["r"]),
+                                             is_sum_merge=True))
+    sd = model.state_dict()
+    sd.update(dparams)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    with torch.no_grad():
+        p = model.decode(inp["X_trgt_enc"], inp["R_trgt"])
+    np.savez_compressed(os.path.join(HERE, "g5_decode_r512.npz"),
+                        loc=p.base_dist.loc.numpy(), scale=p.base_dist.scale.numpy())
+    print("g5_decode_r512: done", p.base_dist.loc.shape)
+
+
+def run_stage_cases():
+    """G6 stage level: MLP, MergeFlatInputs and the scaledot attender in isolation."""
+    rng = np.random.Generator(np.random.Philox(99))
+    f = lambda a: torch.from_numpy(np.asarray(a, dtype="float32"))  # noqa: E731
+    res = {}
+    # scaledot attention, ragged sizes
+    from npf.architectures import get_attender
+    for tag, (B, C, T, d, v) in {"a": (3, 37, 70, 64, 64), "b": (1, 96, 64, 256, 256), "c": (2, 1, 5, 32, 32)}.items():
+        k, q, val = f(rng.standard_normal((B, C, d))), f(rng.standard_normal((B, T, d))), f(rng.standard_normal((B, C, v)))
+        k.requires_grad_(), q.requires_grad_(), val.requires_grad_()
+        att = get_attender("scaledot", d, v, v)
+        o = att(k, q, val)
+        w = f(rng.standard_normal(tuple(o.shape)))
+        (o * w).sum().backward()
+        res.update({f"attn_{tag}/keys": k.detach().numpy(), f"attn_{tag}/queries": q.detach().numpy(),
+                    f"attn_{tag}/values": val.detach().numpy(), f"attn_{tag}/out": o.detach().numpy(),
+                    f"attn_{tag}/w": w.numpy(), f"attn_{tag}/dkeys": k.grad.numpy(),
+                    f"attn_{tag}/dqueries": q.grad.numpy(), f"attn_{tag}/dvalues": val.grad.numpy()})
+    # MLP with the hidden clamp (in 128 -> hidden 256 -> out 128; and 2 -> 32 -> 64)
+    for tag, (n_in, n_out, hid, nl, rows) in {"sq": (64, 64, 64, 3, 77), "clamp": (96, 48, 32, 2, 40),
+                                               "skinny": (2, 64, 32, 1, 100), "wide": (128, 128, 256, 2, 65)}.items():
+        m = MLP(n_in, n_out, hidden_size=hid, n_hidden_layers=nl)
+        sd = {k: f(rng.uniform(-0.3, 0.3, tuple(v.shape))) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        x = f(rng.standard_normal((rows, n_in)))
+        x.requires_grad_()
+        y = m(x)
+        w = f(rng.standard_normal(tuple(y.shape)))
+        (y * w).sum().backward()
+        res.update({f"mlp_{tag}/x": x.detach().numpy(), f"mlp_{tag}/y": y.detach().numpy(), f"mlp_{tag}/w": w.numpy(),
+                    f"mlp_{tag}/dx": x.grad.numpy()})
+        for k, v in sd.items():
+            res[f"mlp_{tag}/param/{k}"] = v.numpy()
+        for k, p in m.named_parameters():
+            res[f"mlp_{tag}/grad/{k}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "g6_stages.npz"), **res)
+    print("g6_stages: done", len(res))
+
+
+def run_pretrained():
+    """G7: shipped checkpoints (r=128, XY-encoder hidden 256) on seeded inputs.  Loaded with
+    ``weights_only=True`` -- nothing from the file is executed."""
+    rng = np.random.Generator(np.random.Philox(7))
+    f = lambda a: torch.from_numpy(np.asarray(a, dtype="float32"))  # noqa: E731
+    B, C, T = 4, 20, 128
+    Xc, Yc, Xt = f(rng.uniform(-1, 1, (B, C, 1))), f(rng.standard_normal((B, C, 1))), f(rng.uniform(-1, 1, (B, T, 1)))
+    res = {"X_cntxt": Xc.numpy(), "Y_cntxt": Yc.numpy(), "X_trgt": Xt.numpy()}
+    path = os.path.join(REF, "results/pretrained/RBF_Kernel/CNP/run_0/params.pt")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    model = npf.CNP(1, 1, r_dim=128,
+                    XYEncoder=merge_flat_input(partial(MLP, n_hidden_layers=2, hidden_size=256), is_sum_merge=True))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    with torch.no_grad():
+        p, *_ = model(Xc, Yc, Xt)
+    res["cnp_loc"], res["cnp_scale"] = p.base_dist.loc.numpy(), p.base_dist.scale.numpy()
+    for k, v in sd.items():
+        res[f"cnp_param/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "g7_pretrained_cnp.npz"), **res)
+    print("g7_pretrained_cnp: done; n_params", sum(v.numel() for v in sd.values()))
+
+
+if __name__ == "__main__":
+    small_full = {"g1_cnp_c1", "g2_lnp_both_c1", "g2_lnp_latent_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64",
+                  "g4s_attnlnp_r64_noqzcct"}
+    for name, case in specs.CASES.items():
+        big = case["r"] >= 256
+        run_case(name, case, store_params=(name == "g1_cnp_c1"), store_full_grads=not big,
+                 adam_step=(name == "g1_cnp_c1"))
+    run_decode_case()
+    run_stage_cases()
+    run_pretrained()

@@ -1,0 +1,112 @@
+"""Shared definitions of the golden cases: model configs, seeded inputs, seeded weights.
+
+Used by ``make_golden.py`` (which runs the *reference* on them, in the build container
+only) and by the tests (which run the oracle / the HIP path on the very same inputs).
+Everything here is this project's own code; nothing is taken from the reference.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import npf_oracle as O  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# name -> dict(kind, r, L_xy, L_dec, dx, dy, B, C, T, extra cfg kwargs)
+CASES = {
+    # G1: config-1 tiny CNP, bit-for-bit gate
+    "g1_cnp_c1": dict(kind="CNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=8, C=32, T=64),
+    # G2: config-1 tiny LNP (both paths), injected eps
+    "g2_lnp_both_c1": dict(kind="LNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=8, C=32, T=64,
+                           encoded_path="both", is_q_zCct=True, n_z=2),
+    "g2_lnp_latent_c1": dict(kind="LNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=8, C=32, T=64,
+                             encoded_path="latent", is_q_zCct=False, n_z=3),
+    # mid-size attentive models with full gradients stored
+    "g3s_attncnp_r64": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=4, C=64, T=96),
+    "g4s_attnlnp_r64": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=4, C=64, T=96,
+                            is_q_zCct=True, n_z=2),
+    "g4s_attnlnp_r64_noqzcct": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=4, C=64, T=96,
+                                    is_q_zCct=False, n_z=1),
+    # G3/G4: config-2 model at reduced batch (weights regenerated from seed, not stored)
+    "g3_attncnp_c2": dict(kind="AttnCNP", r=256, L_xy=4, L_dec=4, dx=1, dy=2, B=2, C=256, T=1024),
+    "g4_attnlnp_c2": dict(kind="AttnLNP", r=256, L_xy=4, L_dec=4, dx=1, dy=2, B=2, C=256, T=1024,
+                          is_q_zCct=True, n_z=1),
+    # G6: edge cases (ragged C/T, C=1, homoskedastic, wider x/y)
+    "g6_attncnp_ragged": dict(kind="AttnCNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=5, T=7),
+    "g6_attncnp_c1pt": dict(kind="AttnCNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=1, T=33),
+    "g6_cnp_homosk": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=2, dy=3, B=3, C=9, T=40,
+                          is_heteroskedastic=False),
+    "g6_cnp_c0": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=0, T=16),
+    "g6_attncnp_c0": dict(kind="AttnCNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=0, T=16),
+    "g6_attncnp_r128": dict(kind="AttnCNP", r=128, L_xy=2, L_dec=4, dx=1, dy=1, B=2, C=50, T=128),
+}
+
+# G5: decode-only, config-5 decoder (r=512, L=4) at reduced batch
+DECODE_CASE = dict(r=512, L_dec=4, dx=1, dy=2, B=2, T=4096)
+
+
+def cfg_of(case: dict) -> O.OracleConfig:
+    return O.OracleConfig(
+        kind=case["kind"], x_dim=case["dx"], y_dim=case["dy"], r_dim=case["r"],
+        encoded_path=case.get("encoded_path"), is_heteroskedastic=case.get("is_heteroskedastic", True),
+        is_q_zCct=case.get("is_q_zCct", False),
+    )
+
+
+def make_params(case: dict, seed: int = 0):
+    cfg = cfg_of(case)
+    p = O.init_params(cfg, seed=seed, n_layers_xy=case["L_xy"], n_layers_dec=case["L_dec"])
+    return O.perturb_biases(p, seed=seed + 1)
+
+
+def make_inputs(case: dict, seed: int = 1234):
+    """X ~ U[-1,1], Y ~ N(0,1), eps ~ N(0,1) from a numpy Philox stream."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    B, C, T, dx, dy = case["B"], case["C"], case["T"], case["dx"], case["dy"]
+    f = lambda a: torch.from_numpy(a.astype("float32"))  # noqa: E731
+    out = dict(
+        X_cntxt=f(rng.uniform(-1, 1, size=(B, C, dx))),
+        Y_cntxt=f(rng.standard_normal(size=(B, C, dy))),
+        X_trgt=f(rng.uniform(-1, 1, size=(B, T, dx))),
+        Y_trgt=f(rng.standard_normal(size=(B, T, dy))),
+    )
+    if case["kind"] in ("LNP", "AttnLNP"):
+        out["eps"] = f(rng.standard_normal(size=(case.get("n_z", 1), B, 1, case["r"])))
+    return out
+
+
+def make_decode_inputs(case: dict = DECODE_CASE, seed: int = 77):
+    """Inputs of the decode-only case: an encoded X_trgt and an attention-style R_trgt."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    B, T, r = case["B"], case["T"], case["r"]
+    f = lambda a: torch.from_numpy(a.astype("float32"))  # noqa: E731
+    return dict(
+        X_trgt_enc=f(rng.standard_normal(size=(B, T, r)) * 0.5),
+        R_trgt=f(rng.standard_normal(size=(1, B, T, r)) * 0.5),
+    )
+
+
+def make_decode_params(case: dict = DECODE_CASE, seed: int = 5):
+    cfg = O.OracleConfig(kind="CNP", x_dim=case["dx"], y_dim=case["dy"], r_dim=case["r"])
+    p = O.init_params(cfg, seed=seed, n_layers_xy=2, n_layers_dec=case["L_dec"])
+    p = O.perturb_biases(p, seed=seed + 1)
+    return cfg, {k: v for k, v in p.items() if k.startswith("decoder.")}
+
+
+def load_golden(name: str) -> dict:
+    with np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def loss_name(case: dict) -> str:
+    if case["kind"] in ("CNP", "AttnCNP"):
+        return "cnpf"
+    return "elbo" if case.get("is_q_zCct", False) else "nll"
