@@ -1,0 +1,180 @@
+/*
+ * npf_hip.h -- C ABI of the MI355X (gfx950) neural-process hot path.
+ *
+ * The reference (MarinerQ/npf_GWwaveform) is 100 % Python and has no FFI; the calls below
+ * are what a maintainer would bind (ctypes) to replace the torch op
+ * sequences of these reference functions (paths relative to the reference root):
+ *
+ *   npf_chain_run        MLP.forward                      npf/architectures/mlp.py:95-109
+ *                        MergeFlatInputs.forward          npf/architectures/encoders.py:175-183
+ *                        BaseAttender.forward / DotAttender.score
+ *                                                         npf/architectures/attention.py:129-164,204-220
+ *                        merge_r_z                        npf/neuralproc/base.py:554-575
+ *                        (and the autograd backward of each: dgrad chains)
+ *   npf_wgrad_run        autograd of nn.Linear weights/biases on the path (mlp.py:84-91) and
+ *                        of torch.bmm / einsum wrt keys/values (attention.py:151,212)
+ *   npf_gauss_head_fwd   NeuralProcessFamily.decode tail  npf/neuralproc/base.py:350-365 (+ :116),
+ *                        pool_and_replicate_middle        npf/neuralproc/helpers.py:21-32,
+ *                        sum_log_prob                     npf/losses.py:18-24
+ *   npf_gauss_head_bwd   autograd of the above
+ *   npf_mean_agg_fwd/bwd torch.mean(R_cntxt, dim=1)       npf/neuralproc/np.py:95, attnnp.py:181
+ *   npf_pack_pt/unpack_pt  layout change at the module boundary (no reference counterpart)
+ *   npf_transpose        W -> W^T for the dgrad chains (no reference counterpart)
+ *
+ * Conventions: plain device pointers + sizes, caller owns all memory, every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*), returns 0 on success and a
+ * negative NPF_E* code otherwise (never throws, never allocates, never synchronises).
+ * All tensors fp32.
+ *
+ * "PT32" layout (the on-device layout between kernels): points are grouped in tiles of 32
+ * (each task padded to whole tiles); a tile of F features (F % 32 == 0) is stored as
+ * [F/4][32 points][4 features], tiles of one task are consecutive, tasks are consecutive:
+ *   elem(task, p, f) = (((task*tiles_per_task + p/32) * (F/4) + f/4) * 32 + p%32) * 4 + f%4
+ * It is exactly the MFMA 32x32 accumulator layout with the point on the lane, so chain
+ * kernels load/store it with fully coalesced 16-byte accesses.
+ */
+#ifndef NPF_HIP_H
+#define NPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPF_OK 0
+#define NPF_EINVAL (-1)   /* bad argument / unsupported size           */
+#define NPF_ELAUNCH (-2)  /* hipLaunch failed (hipGetLastError != 0)    */
+
+#define NPF_MAX_OPS 40
+#define NPF_MAX_FEATURES 256 /* widest activation a chain keeps in registers */
+
+/* ---- chain programs ------------------------------------------------------------- */
+enum npf_opcode {
+  NPF_OP_END = 0,
+  NPF_OP_LOAD_PT = 1,      /* cur <- PT32 tensor p0 (i0 = features F)                          */
+  NPF_OP_STORE_PT = 2,     /* PT32 tensor p0 <- cur (i0 = F)                                   */
+  NPF_OP_LOAD_ROWS = 3,    /* cur <- row-major p0 [task][pt][i0], i0 <= 32, zero padded        */
+  NPF_OP_STORE_ROWS = 4,   /* row-major p0 [task][pt][i0] <- cur features < i0                 */
+  NPF_OP_LINEAR = 5,       /* cur <- act(W cur + b [+ PT addend p2]); see npf_op_t fields       */
+  NPF_OP_SOFTMAX = 6,      /* cur <- softmax over features < i0 of f0*cur                       */
+  NPF_OP_ADD_PT = 7,       /* cur <- cur + PT32 tensor p0 (i0 = F), optional relu (i1)          */
+  NPF_OP_MASK_POS = 8,     /* cur <- (PT32 p0 > 0) ? cur : 0 (i0 = F)      [relu backward]      */
+  NPF_OP_ADD_TASKVEC = 9,  /* cur <- cur + p0[task][i0 features] (row-major), optional relu (i1)*/
+  NPF_OP_ROWDOT_PT = 10,   /* acc0 <- sum_f cur[f] * PT32 p0[f] (i0 = F)   [softmax bwd delta]  */
+  NPF_OP_SOFTMAX_BWD = 11, /* cur <- f0 * P * (cur - acc0), P = PT32 p0 (i0 = F)                */
+  NPF_OP_RELU = 12,        /* cur <- max(cur, 0)                                                */
+  NPF_OP_SCALE = 13        /* cur <- f0 * cur                                                   */
+};
+
+enum npf_wmode {
+  NPF_W_ROWMAJOR = 0, /* W[n][k] at p0 + task*s0 + n*i3 (nn.Linear layout, i3 = row stride)   */
+  NPF_W_PT_ROWS = 1,  /* W[n][k] = PT32 tensor p0 (features = k, points = n) of the WG's task:
+                         the weights of q.k^T are the task's keys                              */
+  NPF_W_PT_COLS = 2   /* W[n][k] = PT32 tensor p0 (features = n, points = k) of the WG's task:
+                         the weights of attn.V are the task's values, transposed              */
+};
+
+#define NPF_F_RELU 1u
+#define NPF_F_ADD_PT 2u /* add PT32 tensor p2 (same F as the output) before the activation     */
+
+typedef struct npf_op {
+  int32_t op;        /* npf_opcode                                                              */
+  int32_t i0;        /* LINEAR: K (valid inputs)        others: see opcode                      */
+  int32_t i1;        /* LINEAR: N (valid outputs)                                               */
+  int32_t i2;        /* LINEAR: npf_wmode                                                       */
+  int32_t i3;        /* LINEAR: row stride of W in floats (mode 0); tiles of the PT weight
+                        tensor per task (modes 1, 2)                                            */
+  uint32_t flags;    /* NPF_F_*                                                                 */
+  float f0;          /* SOFTMAX / SOFTMAX_BWD / SCALE: scale                                    */
+  int32_t i4;        /* *_PT ops and LINEAR addend: task modulus (0 = none): the tensor's task
+                        index is task % i4 (broadcast of X_trgt over n_z samples)               */
+  const void *p0;    /* LINEAR: W                        others: tensor                         */
+  const void *p1;    /* LINEAR: bias or NULL                                                    */
+  const void *p2;    /* LINEAR: PT32 addend or NULL                                             */
+  int64_t s0;        /* LINEAR: per-task stride of W in floats (0 = shared)                     */
+  int64_t s1;        /* LINEAR: per-task stride of bias in floats (0 = shared)                  */
+} npf_op_t;
+
+typedef struct npf_program {
+  int32_t n_ops;
+  int32_t n_tasks;        /* tasks in the batch                                                 */
+  int32_t pts_per_task;   /* valid points per task                                              */
+  int32_t tiles_per_task; /* ceil(pts_per_task / 32)                                            */
+  int32_t wg_per_task;    /* 1: every workgroup (4 tiles) stays inside one task (required by
+                             per-task weights, modes 1/2); 0: tiles are dealt flat               */
+  int32_t reserved[3];
+  npf_op_t ops[NPF_MAX_OPS];
+} npf_program_t;
+
+/* Runs a chain program: every wavefront keeps the activations of one tile of 32 points in
+ * registers (feature-major MFMA accumulator layout) across all ops; weights stream through
+ * LDS.  Replaces the reference functions listed at the top of this file. */
+int npf_chain_run(const npf_program_t *prog, void *stream);
+
+/* ---- weight/bias gradients -------------------------------------------------------- */
+/* One job: dW[n][k] (+)= sum_p dZ[n][p] * A[k][p] and db[n] (+)= sum_p dZ[n][p], where dZ and
+ * A are PT32 tensors with roundup(N,32) / roundup(K,32) features over the same points.
+ * per_task == 0: one dW (row-major, row stride ldw) for all points of all tasks, reduced
+ *                over the workgroups through `partials` (deterministic, no atomics);
+ * per_task == 1: one dW per task, written as a PT32 tensor whose *points* are n and whose
+ *                features are k ([task][ceil(N/32) tiles][roundup(K,32)/4][32][4]): this is
+ *                the gradient of attention keys / values; db is ignored. */
+typedef struct npf_wgrad_job {
+  const float *dZ;
+  const float *A;
+  float *dW;
+  float *db;        /* may be NULL */
+  int64_t ldw;      /* row stride of dW in floats (per_task == 0) */
+  int32_t N, K;
+  int32_t per_task;
+  int32_t accumulate; /* 0: overwrite dW/db, 1: add to them */
+} npf_wgrad_job_t;
+
+#define NPF_MAX_WGRAD_JOBS 16
+/* Runs up to NPF_MAX_WGRAD_JOBS jobs over the same points in ONE launch (+ one reduce). */
+int npf_wgrad_run(const npf_wgrad_job_t *jobs, int32_t n_jobs, int32_t n_tasks, int32_t tiles_per_task,
+                  float *partials, int64_t partials_bytes, void *stream);
+/* Bytes of workspace npf_wgrad_run needs for these jobs (-1 on invalid arguments). */
+int64_t npf_wgrad_partials_bytes(const npf_wgrad_job_t *jobs, int32_t n_jobs, int32_t n_tasks,
+                                 int32_t tiles_per_task);
+
+/* ---- Gaussian head ------------------------------------------------------------------ */
+/* suff: row-major [n_rows][pts][2*dy] raw decoder output.  loc/scale: [n_rows][pts][dy].
+ * scale = 0.01 + 0.99 softplus(raw) (base.py:116); homoskedastic != 0 pools scale over the
+ * points of each row-task (base.py:356-362).  If Y != NULL (row-major [n_y_rows][pts][dy],
+ * row r uses Y[r % n_y_rows]) also writes sum_logp[n_rows] = sum_t sum_dy log N(y|loc,scale)
+ * (losses.py:18-24). */
+int npf_gauss_head_fwd(const float *suff, int32_t n_rows, int32_t pts, int32_t dy, int32_t homoskedastic,
+                       const float *Y, int32_t n_y_rows, float *loc, float *scale, float *sum_logp,
+                       void *stream);
+/* d_suff from (d_loc, d_scale, d_sum_logp): any of the three upstream gradients may be NULL. */
+int npf_gauss_head_bwd(const float *suff, const float *loc, const float *scale, int32_t n_rows, int32_t pts,
+                       int32_t dy, int32_t homoskedastic, const float *Y, int32_t n_y_rows,
+                       const float *d_loc, const float *d_scale, const float *d_sum_logp, float *d_suff,
+                       void *stream);
+
+/* ---- mean aggregation over the points of a task ------------------------------------- */
+/* out[task][F] (row-major) = mean over valid points of PT32 tensor R (np.py:95). */
+int npf_mean_agg_fwd(const float *R_pt, int32_t n_tasks, int32_t pts_per_task, int32_t F, float *out,
+                     void *stream);
+/* dR_pt[task][p][f] = d_out[task][f] / pts_per_task for valid points, 0 for padding. */
+int npf_mean_agg_bwd(const float *d_out, int32_t n_tasks, int32_t pts_per_task, int32_t F, float *dR_pt,
+                     int32_t accumulate, void *stream);
+
+/* ---- layout ----------------------------------------------------------------------- */
+/* rows: row-major [n_tasks][pts_per_task][F_valid]; pt: PT32 with F = roundup(F_valid, 32). */
+int npf_pack_pt(const float *rows, int32_t n_tasks, int32_t pts_per_task, int32_t F_valid, float *pt,
+                void *stream);
+int npf_unpack_pt(const float *pt, int32_t n_tasks, int32_t pts_per_task, int32_t F_valid, float *rows,
+                  void *stream);
+/* dst[c][r] = src[r][c] for a row-major [rows][cols] matrix. */
+int npf_transpose(const float *src, int32_t rows, int32_t cols, float *dst, void *stream);
+
+/* Library / device info. */
+int npf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPF_HIP_H */

@@ -1,0 +1,120 @@
+"""ctypes binding of ``include/npf_hip.h`` (the C ABI of the HIP path).
+
+The library is loaded lazily.  There is no fallback: if ``libnpf_hip.so`` is missing or
+does not load, every entry point raises ``RuntimeError`` -- the product path never runs
+on anything but the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _build
+
+NPF_MAX_OPS = 40
+NPF_MAX_FEATURES = 256
+
+# opcodes (enum npf_opcode)
+OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFTMAX, OP_ADD_PT, OP_MASK_POS, \
+    OP_ADD_TASKVEC, OP_ROWDOT_PT, OP_SOFTMAX_BWD, OP_RELU, OP_SCALE = range(14)
+# weight modes (enum npf_wmode)
+W_ROWMAJOR, W_PT_ROWS, W_PT_COLS = range(3)
+F_RELU, F_ADD_PT = 1, 2
+
+
+class NpfOp(C.Structure):
+    _fields_ = [
+        ("op", C.c_int32), ("i0", C.c_int32), ("i1", C.c_int32), ("i2", C.c_int32), ("i3", C.c_int32),
+        ("flags", C.c_uint32), ("f0", C.c_float), ("i4", C.c_int32),
+        ("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p),
+        ("s0", C.c_int64), ("s1", C.c_int64),
+    ]
+
+
+class NpfProgram(C.Structure):
+    _fields_ = [
+        ("n_ops", C.c_int32), ("n_tasks", C.c_int32), ("pts_per_task", C.c_int32), ("tiles_per_task", C.c_int32),
+        ("wg_per_task", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("ops", NpfOp * NPF_MAX_OPS),
+    ]
+
+
+class NpfWgradJob(C.Structure):
+    _fields_ = [
+        ("dZ", C.c_void_p), ("A", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("ldw", C.c_int64),
+        ("N", C.c_int32), ("K", C.c_int32), ("per_task", C.c_int32), ("accumulate", C.c_int32),
+    ]
+
+
+NPF_MAX_WGRAD_JOBS = 16
+assert C.sizeof(NpfOp) == 72 and C.sizeof(NpfProgram) == 32 + 72 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 56
+
+# name -> (restype, argtypes); must list every symbol declared in include/npf_hip.h
+_i32, _i64, _p = C.c_int32, C.c_int64, C.c_void_p
+SIGNATURES = {
+    "npf_chain_run": (C.c_int, [C.POINTER(NpfProgram), _p]),
+    "npf_wgrad_run": (C.c_int, [C.POINTER(NpfWgradJob), _i32, _i32, _i32, _p, _i64, _p]),
+    "npf_wgrad_partials_bytes": (_i64, [C.POINTER(NpfWgradJob), _i32, _i32, _i32]),
+    "npf_gauss_head_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p]),
+    "npf_gauss_head_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    "npf_mean_agg_fwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "npf_mean_agg_bwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
+    "npf_pack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "npf_unpack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "npf_transpose": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "npf_version": (C.c_int, []),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load ``libnpf_hip.so`` (built by ``_build.build()``); raise loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"HIP extension {path} is missing. Build it with `python -m npf_gwwaveform_amd._build` "
+            "(needs hipcc); there is no CPU fallback for the neural-process path."
+        )
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise RuntimeError(f"HIP extension {path} failed to load: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with status {rc} "
+                           f"({'invalid argument/unsupported size' if rc == -1 else 'kernel launch error'})")
+
+
+def stream_ptr(device: Optional[torch.device] = None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("the HIP path takes device tensors only (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"the HIP path computes in fp32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor handed to the HIP path must be contiguous")
+    return t.data_ptr()

@@ -1,0 +1,205 @@
+"""Building blocks of the neural-process path with the reference's module interface
+(constructor arguments, ``forward`` signatures, ``state_dict`` keys) and HIP execution.
+
+Mirrors, for the hot path only:
+  * ``MLP``                     npf/architectures/mlp.py:12-115
+  * ``MergeFlatInputs`` / ``merge_flat_input`` (``is_sum_merge=True``)
+                                npf/architectures/encoders.py:130-213
+  * ``get_attender("scaledot")`` / ``DotAttender``
+                                npf/architectures/attention.py:16-86,89-220
+Everything else the reference offers in those files (other activations, dropout,
+residual MLPs, concatenating merge, the other attention flavours) raises
+``NotImplementedError`` here instead of silently running somewhere else.
+
+``forward`` takes row-major device tensors like the reference; internally every module can
+also append itself to a :class:`~npf_gwwaveform_amd.chain.Chain` (``append_to``), which is how
+the models fuse whole stages into one kernel launch.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as FN
+from .chain import Chain
+
+__all__ = ["MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "get_attender"]
+
+
+def _check_relu(activation) -> None:
+    if not isinstance(activation, nn.ReLU):
+        # the reference itself only works with ReLU-family activations on this path
+        # (npf/utils/initialization.py:34-50 raises for anything outside its mapper)
+        raise NotImplementedError("the HIP path implements the reference's ReLU MLPs only")
+
+
+class MLP(nn.Module):
+    """``MLP(input_size, output_size, hidden_size=32, n_hidden_layers=1, ...)``: to_hidden ->
+    ReLU -> (n_hidden_layers - 1) x [Linear -> ReLU] -> out; hidden size clamped as in
+    npf/architectures/mlp.py:64-79."""
+
+    def __init__(self, input_size, output_size, hidden_size=32, n_hidden_layers=1, activation=None, is_bias=True,
+                 dropout=0, is_force_hid_smaller=False, is_res=False):
+        super().__init__()
+        activation = nn.ReLU() if activation is None else activation
+        _check_relu(activation)
+        if dropout != 0:
+            raise NotImplementedError("dropout is not on the hot path (the reference's 1-D models use dropout=0)")
+        if is_res:
+            raise NotImplementedError("residual MLPs are not on the hot path")
+        self.input_size, self.output_size, self.n_hidden_layers, self.is_res = input_size, output_size, n_hidden_layers, is_res
+        self.hidden_size = hidden_size
+        if is_force_hid_smaller and self.hidden_size > max(output_size, input_size):
+            self.hidden_size = max(output_size, input_size)
+            warnings.warn(f"hidden_size={hidden_size} larger than output={output_size} and input={input_size}. "
+                          f"Setting it to {self.hidden_size}.")
+        elif self.hidden_size < min(output_size, input_size):
+            self.hidden_size = min(output_size, input_size)
+            warnings.warn(f"hidden_size={hidden_size} smaller than output={output_size} and input={input_size}. "
+                          f"Setting it to {self.hidden_size}.")
+        self.dropout = nn.Identity()
+        self.activation = activation
+        self.to_hidden = nn.Linear(input_size, self.hidden_size, bias=is_bias)
+        self.linears = nn.ModuleList(
+            [nn.Linear(self.hidden_size, self.hidden_size, bias=is_bias) for _ in range(n_hidden_layers - 1)])
+        self.out = nn.Linear(self.hidden_size, output_size, bias=is_bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """Effective initialisation of the reference (SURVEY.md 8a row 12;
+        npf/utils/initialization.py:34-94): hidden layers keep torch's default weight
+        init with zeroed biases, ``out`` gets kaiming-uniform(relu) and a zero bias."""
+        for lin in [self.to_hidden, *self.linears]:
+            if lin.bias is not None:
+                lin.bias.data.zero_()
+        if self.out.bias is not None:
+            self.out.bias.data.zero_()
+        nn.init.kaiming_uniform_(self.out.weight, nonlinearity="relu")
+
+    def layers(self):
+        return [self.to_hidden, *self.linears, self.out]
+
+    def append_to(self, ch: Chain, first_addend=None, first_addend_modulus=0) -> Chain:
+        ls = self.layers()
+        for j, lin in enumerate(ls):
+            ch.linear(lin.weight, lin.bias, relu=(j < len(ls) - 1))
+        return ch
+
+    def forward(self, x):
+        lead, n_in = x.shape[:-1], x.shape[-1]
+        rows = int(math.prod(lead)) if len(lead) else 1
+        if rows == 0:
+            return x.new_zeros(*lead, self.output_size)
+        ch = Chain(1, rows, x.device)
+        ch.input_pt(FN.pack_pt(x.reshape(1, rows, n_in)), n_in)
+        self.append_to(ch).output_pt()
+        (y,) = ch.run()
+        return FN.unpack_pt(y, rows, self.output_size).reshape(*lead, self.output_size)
+
+
+class MergeFlatInputs(nn.Module):
+    """Two-input wrapper, sum-merge flavour: ``flat_module(relu(x1 + resizer(x2)))``
+    (npf/architectures/encoders.py:130-183)."""
+
+    def __init__(self, FlatModule, x1_dim, x2_dim, n_out, is_sum_merge=False, **kwargs):
+        super().__init__()
+        if not is_sum_merge:
+            raise NotImplementedError("only is_sum_merge=True (the reference's default encoders/decoders) is on the hot path")
+        self.is_sum_merge = True
+        self.resizer = MLP(x2_dim, x1_dim)
+        self.flat_module = FlatModule(x1_dim, n_out, **kwargs)
+        if not isinstance(self.flat_module, MLP):
+            raise NotImplementedError("the HIP path needs an MLP as the flat module")
+
+    def reset_parameters(self):  # the reference's weights_init is a no-op here
+        pass
+
+    def append_to(self, ch: Chain, x1_pt: Optional[torch.Tensor] = None, x1_modulus: int = 0,
+                  x1_taskvec: bool = False) -> Chain:
+        """cur = x2 on entry.  ``x1_pt``: PT32 tensor added before the ReLU."""
+        rl = self.resizer.layers()
+        for j, lin in enumerate(rl[:-1]):
+            ch.linear(lin.weight, lin.bias, relu=True)
+        ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=x1_modulus)
+        return self.flat_module.append_to(ch)
+
+    def forward(self, x1, x2):
+        # row-major API: x1 [..., T, x1_dim]; x2 broadcastable to it with optional extra leading dims
+        if x2.dim() < x1.dim():
+            raise NotImplementedError("x2 must have at least as many dims as x1")
+        T, d1 = x1.shape[-2], x1.shape[-1]
+        lead2 = x2.shape[:-2]
+        n2 = int(math.prod(lead2)) if len(lead2) else 1
+        n1 = int(math.prod(x1.shape[:-2])) if x1.dim() > 2 else 1
+        if n2 % max(n1, 1) != 0:
+            raise NotImplementedError("unsupported broadcast between x1 and x2")
+        x2 = x2.expand(*lead2, T, x2.shape[-1]) if x2.shape[-2] != T else x2
+        n_out = self.flat_module.output_size
+        if T == 0 or n2 == 0:
+            return x1.new_zeros(*lead2, T, n_out)
+        ch = Chain(n2, T, x1.device)
+        ch.input_pt(FN.pack_pt(x2.reshape(n2, T, x2.shape[-1])), x2.shape[-1])
+        self.append_to(ch, FN.pack_pt(x1.reshape(n1, T, d1)), x1_modulus=(n1 if n1 != n2 else 0)).output_pt()
+        (y,) = ch.run()
+        return FN.unpack_pt(y, T, n_out).reshape(*lead2, T, n_out)
+
+
+def merge_flat_input(module, is_sum_merge=False, **kwargs):
+    """Factory with the reference's calling convention
+    (npf/architectures/encoders.py:186-213): ``merge_flat_input(MLP, is_sum_merge=True)(x_dim, flat_dim, n_out)``."""
+
+    def merged_flat_input(x_shape, flat_dim, n_out, **kwargs2):
+        assert isinstance(x_shape, int)
+        return MergeFlatInputs(module, x_shape, flat_dim, n_out, is_sum_merge=is_sum_merge, **kwargs2, **kwargs)
+
+    return merged_flat_input
+
+
+class DotAttender(nn.Module):
+    """Scaled dot-product cross attention without learned projections:
+    ``softmax(Q K^T / sqrt(d)) V`` (npf/architectures/attention.py:89-220)."""
+
+    def __init__(self, kq_size, value_size, out_size, is_scale=True, is_normalize=True, dropout=0):
+        super().__init__()
+        if not is_normalize or dropout != 0:
+            raise NotImplementedError("un-normalised or dropout attention is not on the hot path")
+        if value_size != out_size:
+            raise NotImplementedError("attention output resizer (value_size != out_size) is not on the hot path")
+        self.kq_size, self.value_size, self.out_size, self.is_scale = kq_size, value_size, out_size, is_scale
+        self.is_normalize, self.is_resize = True, False
+        self.dropout = nn.Identity()
+
+    def append_to(self, ch: Chain, keys_pt, values_pt, n_keys: int) -> Chain:
+        """cur = queries on entry, context vectors on exit."""
+        scale = 1.0 / math.sqrt(self.kq_size) if self.is_scale else 1.0
+        return ch.attn_scores(keys_pt, n_keys).softmax(scale).attn_values(values_pt, self.value_size)
+
+    def forward(self, keys, queries, values):
+        B, C, d = keys.shape
+        T = queries.shape[1]
+        if keys.dim() != 3 or queries.dim() != 3:
+            raise NotImplementedError("relative-position (4-D) keys are not on the hot path")
+        if C == 0:
+            raise ValueError("attention over zero keys")
+        ch = Chain(B, T, keys.device, wg_per_task=True)
+        ch.input_pt(FN.pack_pt(queries), d)
+        self.append_to(ch, FN.pack_pt(keys), FN.pack_pt(values), C).output_pt()
+        (o,) = ch.run()
+        return FN.unpack_pt(o, T, self.out_size)
+
+
+def get_attender(attention, kq_size, value_size, out_size, **kwargs):
+    """``get_attender`` of npf/architectures/attention.py:16-86 for the hot path."""
+    if not isinstance(attention, str):
+        return attention(kq_size, value_size, out_size, **kwargs)
+    attention = attention.lower()
+    if attention == "scaledot":
+        return DotAttender(kq_size, value_size, out_size, is_scale=True, **kwargs)
+    if attention in ("multiplicative", "additive", "cosine", "manhattan", "euclidean", "weighted_dist", "multihead",
+                     "transformer"):
+        raise NotImplementedError(f"attention={attention!r} is not on the MI355X hot path yet (scaledot only)")
+    raise ValueError("Unknown attention method {}".format(attention))

@@ -1,0 +1,467 @@
+"""Host runtime of the HIP chain kernel: describe a per-point computation once, get the
+forward program, the backward (dgrad) program and the weight-gradient jobs from it.
+
+A :class:`Chain` is a straight-line computation on the register-resident activation of
+every point (``cur`` in ``csrc/chain_kernel.hip``): inputs, Linear layers (shared weights
+or the task's keys / values as weights), softmax, adds.  ``Chain.run()`` executes it through
+``npf_chain_run`` inside one ``torch.autograd.Function``; the backward pass is the chain
+walked in reverse (relu masks, transposed weights) plus one batched ``npf_wgrad_run``.
+
+Tensors between chains are "PT32" tensors: ``[n_tasks, tiles, F/4, 32, 4]`` fp32 (see
+``include/npf_hip.h``).  Nothing here computes on the CPU: every step is a kernel launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def tiles_of(pts: int) -> int:
+    return (pts + 31) // 32
+
+
+def pt_shape(n_tasks: int, pts: int, F: int):
+    return (n_tasks, tiles_of(pts), pad32(F) // 4, 32, 4)
+
+
+def pt_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
+    return torch.empty(pt_shape(n_tasks, pts, F), dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------------------------------
+# low level: program assembly + launch
+# ---------------------------------------------------------------------------------------
+class Program:
+    """A list of ``npf_op_t`` + geometry; ``launch()`` calls ``npf_chain_run``."""
+
+    def __init__(self, n_tasks: int, pts_per_task: int, wg_per_task: bool):
+        self.n_tasks, self.pts, self.wg_per_task = n_tasks, pts_per_task, wg_per_task
+        self.ops: List[L.NpfOp] = []
+        self.keep: list = []  # tensors referenced by raw pointer must outlive the launch call
+
+    def _op(self, **kw) -> None:
+        if len(self.ops) >= L.NPF_MAX_OPS:
+            raise RuntimeError(f"chain program longer than NPF_MAX_OPS={L.NPF_MAX_OPS}")
+        o = L.NpfOp()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        self.ops.append(o)
+
+    def _p(self, t: Optional[torch.Tensor]):
+        if t is None:
+            return None
+        self.keep.append(t)
+        return L.ptr(t)
+
+    def load_pt(self, t, F, modulus=0):
+        self._op(op=L.OP_LOAD_PT, i0=pad32(F), i4=modulus, p0=self._p(t))
+
+    def store_pt(self, t, F):
+        self._op(op=L.OP_STORE_PT, i0=pad32(F), p0=self._p(t))
+
+    def add_pt(self, t, F, relu=False, modulus=0):
+        self._op(op=L.OP_ADD_PT, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
+
+    def mask_pos(self, t, F):
+        self._op(op=L.OP_MASK_POS, i0=pad32(F), p0=self._p(t))
+
+    def rowdot_pt(self, t, F):
+        self._op(op=L.OP_ROWDOT_PT, i0=pad32(F), p0=self._p(t))
+
+    def softmax_bwd(self, t, F, scale):
+        self._op(op=L.OP_SOFTMAX_BWD, i0=pad32(F), f0=scale, p0=self._p(t))
+
+    def load_rows(self, t, kd, modulus=0):
+        self._op(op=L.OP_LOAD_ROWS, i0=kd, i4=modulus, p0=self._p(t))
+
+    def store_rows(self, t, nd):
+        self._op(op=L.OP_STORE_ROWS, i0=nd, p0=self._p(t))
+
+    def softmax(self, n_valid, scale):
+        self._op(op=L.OP_SOFTMAX, i0=n_valid, f0=scale)
+
+    def add_taskvec(self, t, F, relu=False, modulus=0):
+        self._op(op=L.OP_ADD_TASKVEC, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
+
+    def linear(self, W, K, N, bias=None, relu=False, addend=None, addend_modulus=0, mode=L.W_ROWMAJOR, ldw=None,
+               w_tiles=0, w_task_stride=0, b_task_stride=0):
+        flags = (L.F_RELU if relu else 0) | (L.F_ADD_PT if addend is not None else 0)
+        i3 = (ldw if ldw is not None else K) if mode == L.W_ROWMAJOR else w_tiles
+        self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=mode, i3=i3, flags=flags, i4=addend_modulus, p0=self._p(W),
+                 p1=self._p(bias), p2=self._p(addend), s0=w_task_stride, s1=b_task_stride)
+
+    def launch(self) -> None:
+        if not self.ops:
+            return
+        prog = L.NpfProgram()
+        prog.n_ops = len(self.ops)
+        prog.n_tasks, prog.pts_per_task, prog.tiles_per_task = self.n_tasks, self.pts, tiles_of(self.pts)
+        prog.wg_per_task = int(self.wg_per_task)
+        for i, o in enumerate(self.ops):
+            prog.ops[i] = o
+        L.check(L.load().npf_chain_run(C.byref(prog), L.stream_ptr()), "npf_chain_run")
+
+
+def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
+    """jobs: dicts(dZ, A, N, K, dW, db=None, ldw=None, per_task=False, accumulate=False)."""
+    if not jobs:
+        return
+    lib = L.load()
+    for i0 in range(0, len(jobs), L.NPF_MAX_WGRAD_JOBS):
+        chunk = jobs[i0:i0 + L.NPF_MAX_WGRAD_JOBS]
+        arr = (L.NpfWgradJob * len(chunk))()
+        for j, jb in enumerate(chunk):
+            arr[j].dZ, arr[j].A, arr[j].dW = L.ptr(jb["dZ"]), L.ptr(jb["A"]), L.ptr(jb["dW"])
+            arr[j].db = L.ptr(jb.get("db"))
+            arr[j].ldw = jb.get("ldw") or jb["K"]
+            arr[j].N, arr[j].K = jb["N"], jb["K"]
+            arr[j].per_task = int(jb.get("per_task", False))
+            arr[j].accumulate = int(jb.get("accumulate", False))
+        nbytes = lib.npf_wgrad_partials_bytes(arr, len(chunk), n_tasks, tiles_of(pts))
+        if nbytes < 0:
+            raise RuntimeError("npf_wgrad_partials_bytes: invalid wgrad jobs")
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        L.check(lib.npf_wgrad_run(arr, len(chunk), n_tasks, tiles_of(pts), L.ptr(ws), nbytes, L.stream_ptr()),
+                "npf_wgrad_run")
+
+
+def transpose(W: torch.Tensor) -> torch.Tensor:
+    """W^T of a row-major [rows, cols] device matrix (npf_transpose)."""
+    rows, cols = W.shape
+    out = torch.empty((cols, rows), dtype=torch.float32, device=W.device)
+    L.check(L.load().npf_transpose(L.ptr(W.contiguous()), rows, cols, L.ptr(out), L.stream_ptr()), "npf_transpose")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# chain description
+# ---------------------------------------------------------------------------------------
+@dataclass
+class _Step:
+    kind: str
+    t: dict = field(default_factory=dict)   # role -> index into Chain.tensors
+    a: dict = field(default_factory=dict)   # static attributes
+
+
+class Chain:
+    """Straight-line per-point computation (see module docstring).
+
+    ``n_tasks`` x ``pts_per_task`` points; ``wg_per_task`` must be True when the chain uses
+    the task's keys / values as weights (attention)."""
+
+    def __init__(self, n_tasks: int, pts_per_task: int, device, wg_per_task: bool = False):
+        self.n_tasks, self.pts, self.device, self.wg_per_task = n_tasks, pts_per_task, device, wg_per_task
+        self.steps: List[_Step] = []
+        self.tensors: List[Optional[torch.Tensor]] = []
+        self.F = 0  # valid features of cur
+
+    def _t(self, t: Optional[torch.Tensor]) -> int:
+        if t is None:
+            return -1
+        self.tensors.append(t)
+        return len(self.tensors) - 1
+
+    # ---- inputs
+    def input_pt(self, t: torch.Tensor, F: int, modulus: int = 0) -> "Chain":
+        self.steps.append(_Step("input_pt", {"x": self._t(t)}, {"F": F, "mod": modulus}))
+        self.F = F
+        return self
+
+    def input_rows(self, t: torch.Tensor, kd: int, modulus: int = 0) -> "Chain":
+        if kd > 32:
+            raise NotImplementedError("row-major chain inputs are limited to 32 features")
+        self.steps.append(_Step("input_rows", {"x": self._t(t)}, {"kd": kd, "mod": modulus}))
+        self.F = kd
+        return self
+
+    # ---- layers
+    def linear(self, W: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
+               addend: Optional[torch.Tensor] = None, addend_modulus: int = 0) -> "Chain":
+        N, K = W.shape
+        if K != self.F:
+            raise ValueError(f"Linear expects {K} inputs, chain carries {self.F}")
+        if max(N, K) > L.NPF_MAX_FEATURES:
+            raise NotImplementedError(
+                f"layer {K}->{N}: the HIP chain keeps at most {L.NPF_MAX_FEATURES} features in registers")
+        self.steps.append(_Step("linear", {"W": self._t(W), "b": self._t(b), "add": self._t(addend)},
+                                {"N": N, "K": K, "relu": relu, "mod": addend_modulus}))
+        self.F = N
+        return self
+
+    def add_pt(self, t: torch.Tensor, relu: bool = False, modulus: int = 0) -> "Chain":
+        self.steps.append(_Step("add_pt", {"x": self._t(t)}, {"F": self.F, "relu": relu, "mod": modulus}))
+        return self
+
+    def add_taskvec(self, v: torch.Tensor, relu: bool = False, modulus: int = 0) -> "Chain":
+        """cur += v[task] with v row-major [n_tasks (or modulus), pad32(F)]."""
+        self.steps.append(_Step("add_taskvec", {"v": self._t(v)}, {"F": self.F, "relu": relu, "mod": modulus}))
+        return self
+
+    def attn_scores(self, keys_pt: torch.Tensor, n_keys: int) -> "Chain":
+        """cur[c] <- sum_d keys[c][d] cur[d] (DotAttender.score, attention.py:204-220, unscaled)."""
+        if not self.wg_per_task:
+            raise ValueError("attention needs wg_per_task=True")
+        if n_keys > L.NPF_MAX_FEATURES:
+            raise NotImplementedError(f"more than {L.NPF_MAX_FEATURES} context points per task are not supported yet")
+        self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F}))
+        self.F = n_keys
+        return self
+
+    def softmax(self, scale: float) -> "Chain":
+        self.steps.append(_Step("softmax", {}, {"n": self.F, "scale": float(scale)}))
+        return self
+
+    def attn_values(self, values_pt: torch.Tensor, r: int) -> "Chain":
+        """cur[n] <- sum_c values[c][n] cur[c] (torch.bmm(attn, values), attention.py:151)."""
+        self.steps.append(_Step("attn_values", {"v": self._t(values_pt)}, {"C": self.F, "r": r}))
+        self.F = r
+        return self
+
+    # ---- outputs
+    def tap(self) -> "Chain":
+        self.steps.append(_Step("tap", {}, {"F": self.F}))
+        return self
+
+    def output_pt(self) -> "Chain":
+        self.steps.append(_Step("output_pt", {}, {"F": self.F}))
+        return self
+
+    def output_rows(self) -> "Chain":
+        if self.F > 32:
+            raise NotImplementedError("row-major chain outputs are limited to 32 features")
+        self.steps.append(_Step("output_rows", {}, {"nd": self.F}))
+        return self
+
+    def run(self):
+        """Execute; returns the tuple of outputs in declaration order (taps and final)."""
+        self.grad_enabled = torch.is_grad_enabled()
+        outs = _ChainFn.apply(self, *[t for t in self.tensors])
+        return outs
+
+
+class _ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, chain: Chain, *tensors):
+        needs_grad = [t is not None and t.requires_grad for t in chain.tensors]
+        if not chain.grad_enabled:
+            needs_grad = [False] * len(needs_grad)
+        train = any(needs_grad)  # (grad mode is always off inside Function.forward)
+        prog = Program(chain.n_tasks, chain.pts, chain.wg_per_task)
+        dev = chain.device
+        T = [t.detach() if t is not None else None for t in chain.tensors]
+        ctx_tiles = lambda k: T[k].shape[1]  # noqa: E731
+
+        saved = {}      # (step index, role) -> PT tensor
+        outputs = []
+        backed = None   # PT tensor currently holding cur (None if cur only lives in registers)
+        upstream = False  # does cur depend on something that needs a gradient
+        upstream_before = []
+
+        def ensure_saved(F):
+            nonlocal backed
+            if backed is None:
+                backed = pt_empty(chain.n_tasks, chain.pts, F, dev)
+                prog.store_pt(backed, F)
+            return backed
+
+        for i, st in enumerate(chain.steps):
+            upstream_before.append(upstream)
+            k, a = st.kind, st.a
+            if k == "input_pt":
+                prog.load_pt(T[st.t["x"]], a["F"], a["mod"])
+                backed = T[st.t["x"]] if a["mod"] == 0 else None
+                upstream = needs_grad[st.t["x"]]
+            elif k == "input_rows":
+                prog.load_rows(T[st.t["x"]], a["kd"], a["mod"])
+                backed = None
+                upstream = False
+            elif k == "linear":
+                W, b, add = st.t["W"], st.t["b"], st.t["add"]
+                if train and (needs_grad[W] or (b >= 0 and needs_grad[b])):
+                    saved[(i, "in")] = ensure_saved(a["K"])
+                prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
+                            addend=T[add] if add >= 0 else None, addend_modulus=a["mod"])
+                backed = None
+                upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
+                if train and a["relu"] and upstream:
+                    saved[(i, "out")] = ensure_saved(a["N"])
+            elif k == "add_pt":
+                prog.add_pt(T[st.t["x"]], a["F"], a["relu"], a["mod"])
+                backed = None
+                upstream = upstream or needs_grad[st.t["x"]]
+                if train and a["relu"] and upstream:
+                    saved[(i, "out")] = ensure_saved(a["F"])
+            elif k == "add_taskvec":
+                prog.add_taskvec(T[st.t["v"]], a["F"], a["relu"], a["mod"])
+                backed = None
+                upstream = upstream or needs_grad[st.t["v"]]
+                if train and a["relu"] and upstream:
+                    saved[(i, "out")] = ensure_saved(a["F"])
+            elif k == "attn_scores":
+                kk = st.t["k"]
+                if train and needs_grad[kk]:
+                    saved[(i, "in")] = ensure_saved(a["r"])
+                prog.linear(T[kk], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=ctx_tiles(kk))
+                backed = None
+                upstream = upstream or needs_grad[kk]
+            elif k == "softmax":
+                prog.softmax(a["n"], a["scale"])
+                backed = None
+                if train and upstream:
+                    saved[(i, "out")] = ensure_saved(a["n"])
+            elif k == "attn_values":
+                vv = st.t["v"]
+                if train and needs_grad[vv]:
+                    saved[(i, "in")] = ensure_saved(a["C"])
+                prog.linear(T[vv], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=ctx_tiles(vv))
+                backed = None
+                upstream = upstream or needs_grad[vv]
+            elif k in ("tap", "output_pt"):
+                # an output must own its storage: never alias an input tensor
+                if backed is not None and any(backed is t for t in T):
+                    backed = None
+                outputs.append(ensure_saved(a["F"]))
+            elif k == "output_rows":
+                o = torch.empty((chain.n_tasks, chain.pts, a["nd"]), dtype=torch.float32, device=dev)
+                prog.store_rows(o, a["nd"])
+                outputs.append(o)
+            else:  # pragma: no cover
+                raise AssertionError(k)
+        prog.launch()
+        ctx.chain, ctx.saved, ctx.T, ctx.needs_grad, ctx.upstream_before = chain, saved, T, needs_grad, upstream_before
+        ctx.train = train
+        return tuple(outputs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        chain: Chain = ctx.chain
+        saved, T, needs_grad, upstream_before = ctx.saved, ctx.T, ctx.needs_grad, ctx.upstream_before
+        dev = chain.device
+        prog = Program(chain.n_tasks, chain.pts, chain.wg_per_task)
+        grads: List[Optional[torch.Tensor]] = [None] * len(T)
+        pending_taskvec = []  # (tensor index, PT buffer, F, modulus): reduced over the points after the launch
+        jobs = []
+        gouts = list(gouts)
+        started = False  # has cur been initialised with a gradient yet
+
+        def new_pt(F):
+            return pt_empty(chain.n_tasks, chain.pts, F, dev)
+
+        def acc_grad(idx, g):
+            grads[idx] = g if grads[idx] is None else grads[idx] + g
+
+        def reduce_modulus(buf, mod):
+            if mod and mod != chain.n_tasks:
+                return buf.view(chain.n_tasks // mod, mod, *buf.shape[1:]).sum(0)
+            return buf
+
+        n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows"))
+        assert len(gouts) == n_out
+        for i in range(len(chain.steps) - 1, -1, -1):
+            st = chain.steps[i]
+            k, a = st.kind, st.a
+            if k in ("output_pt", "output_rows", "tap"):
+                g = gouts.pop()
+                if g is None:
+                    continue
+                g = g.contiguous()
+                if k == "output_rows":
+                    assert not started
+                    prog.load_rows(g, a["nd"])
+                elif not started:
+                    prog.load_pt(g, a["F"])
+                else:
+                    prog.add_pt(g, a["F"])
+                started = True
+                continue
+            if not started:
+                continue  # no gradient reaches this step
+            if k == "linear":
+                W, b, add = st.t["W"], st.t["b"], st.t["add"]
+                if a["relu"]:
+                    prog.mask_pos(saved[(i, "out")], a["N"])
+                need_dz = needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
+                if need_dz:
+                    dz = new_pt(a["N"])
+                    prog.store_pt(dz, a["N"])
+                    if needs_grad[W] or (b >= 0 and needs_grad[b]):
+                        dW = torch.empty_like(T[W])
+                        db = torch.empty_like(T[b]) if b >= 0 else None
+                        jobs.append(dict(dZ=dz, A=saved[(i, "in")], N=a["N"], K=a["K"], dW=dW, db=db))
+                        grads[W] = dW
+                        if b >= 0:
+                            grads[b] = db
+                    if add >= 0 and needs_grad[add]:
+                        grads[add] = (dz, a["mod"])  # resolved after the launch
+                if upstream_before[i]:
+                    Wt = transpose(T[W])  # [K, N]
+                    prog.linear(Wt, a["N"], a["K"])
+                else:
+                    started = False  # nothing upstream needs this gradient
+                    break
+            elif k in ("add_pt", "add_taskvec"):
+                if a["relu"]:
+                    prog.mask_pos(saved[(i, "out")], a["F"])
+                idx = st.t["x"] if k == "add_pt" else st.t["v"]
+                if needs_grad[idx]:
+                    buf = new_pt(a["F"])
+                    prog.store_pt(buf, a["F"])
+                    if k == "add_pt":
+                        grads[idx] = (buf, a["mod"])
+                    else:
+                        pending_taskvec.append((idx, buf, a["F"], a["mod"]))
+            elif k == "attn_values":
+                vv = st.t["v"]
+                if needs_grad[vv]:
+                    dO = new_pt(a["r"])
+                    prog.store_pt(dO, a["r"])
+                    dV = torch.empty_like(T[vv])
+                    jobs.append(dict(dZ=saved[(i, "in")], A=dO, N=a["C"], K=a["r"], dW=dV, per_task=True))
+                    grads[vv] = dV
+                prog.linear(T[vv], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=T[vv].shape[1])
+            elif k == "softmax":
+                P = saved[(i, "out")]
+                prog.rowdot_pt(P, a["n"])
+                prog.softmax_bwd(P, a["n"], a["scale"])
+            elif k == "attn_scores":
+                kk = st.t["k"]
+                if needs_grad[kk]:
+                    dS = new_pt(a["C"])
+                    prog.store_pt(dS, a["C"])
+                    dK = torch.empty_like(T[kk])
+                    jobs.append(dict(dZ=dS, A=saved[(i, "in")], N=a["C"], K=a["r"], dW=dK, per_task=True))
+                    grads[kk] = dK
+                if upstream_before[i]:
+                    prog.linear(T[kk], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=T[kk].shape[1])
+                else:
+                    break
+            elif k == "input_pt":
+                idx = st.t["x"]
+                if needs_grad[idx]:
+                    buf = new_pt(a["F"])
+                    prog.store_pt(buf, a["F"])
+                    grads[idx] = (buf, a["mod"])
+            elif k == "input_rows":
+                pass
+        prog.launch()
+        run_wgrad(jobs, chain.n_tasks, chain.pts, dev)
+        from .functional import sum_points_pt  # late import (cycle)
+
+        for idx, buf, F, mod in pending_taskvec:
+            g = sum_points_pt(buf, chain.pts, F)  # [n_tasks, pad32(F)]
+            acc_grad(idx, reduce_modulus(g, mod))
+        out = []
+        for g in grads:
+            if isinstance(g, tuple):
+                g = reduce_modulus(g[0], g[1])
+            out.append(g)
+        return (None, *out)

@@ -1,0 +1,155 @@
+// Layout changes at the module boundary (row-major torch tensors <-> PT32), the weight
+// transpose used by the dgrad chains, and the mean aggregation over a task's points
+// (torch.mean(R_cntxt, dim=1): npf/neuralproc/np.py:95, attnnp.py:181).  All HBM-bound,
+// one float4 per thread, coalesced on the PT32 side.
+#include "npf_common.hpp"
+
+namespace npf {
+
+__global__ void pack_pt_kernel(const float* __restrict__ rows, int n_tasks, int pts, int Fv, int Fp, float* __restrict__ pt) {
+  const int tiles = (pts + 31) / 32;
+  const size_t total = (size_t)n_tasks * tiles * (Fp / 4) * 32;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int p = idx & 31;
+    const size_t r = idx >> 5;
+    const int f4 = r % (Fp / 4);
+    const size_t tt = r / (Fp / 4);  // task * tiles + tile
+    const int tile = tt % tiles;
+    const size_t task = tt / tiles;
+    const int point = tile * 32 + p;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (point < pts) {
+      const float* src = rows + (task * pts + point) * (size_t)Fv + 4 * f4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * f4 + j < Fv) v[j] = src[j];
+    }
+    *(f32x4*)(pt + idx * 4) = v;
+  }
+}
+
+__global__ void unpack_pt_kernel(const float* __restrict__ pt, int n_tasks, int pts, int Fv, int Fp, float* __restrict__ rows) {
+  const int tiles = (pts + 31) / 32;
+  const size_t total = (size_t)n_tasks * tiles * (Fp / 4) * 32;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int p = idx & 31;
+    const size_t r = idx >> 5;
+    const int f4 = r % (Fp / 4);
+    const size_t tt = r / (Fp / 4);
+    const int tile = tt % tiles;
+    const size_t task = tt / tiles;
+    const int point = tile * 32 + p;
+    if (point < pts) {
+      const f32x4 v = *(const f32x4*)(pt + idx * 4);
+      float* dst = rows + (task * pts + point) * (size_t)Fv + 4 * f4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * f4 + j < Fv) dst[j] = v[j];
+    }
+  }
+}
+
+// 32x32 LDS tile transpose
+__global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(size_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+// out[task][f] = mean over valid points.  grid = (ceil(F/32), n_tasks); 256 threads = 8 feature quads x 32 points.
+__global__ void mean_agg_fwd_kernel(const float* __restrict__ R, int pts, int F, float* __restrict__ out) {
+  const int tiles = (pts + 31) / 32;
+  const int p = threadIdx.x & 31, f4 = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const size_t task = blockIdx.y;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (f4 < F / 4) {
+    const float* base = R + task * tiles * (size_t)(F * 32) + pt_off(f4, p);
+    for (int t = 0; t < tiles; ++t)
+      if (t * 32 + p < pts) s += *(const f32x4*)(base + (size_t)t * F * 32);
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], off);
+  if (p == 0 && f4 < F / 4) *(f32x4*)(out + task * F + 4 * f4) = s * (1.f / (float)pts);
+}
+
+__global__ void mean_agg_bwd_kernel(const float* __restrict__ d_out, int n_tasks, int pts, int F, float* __restrict__ dR,
+                                    int accumulate) {
+  const int tiles = (pts + 31) / 32;
+  const size_t total = (size_t)n_tasks * tiles * (F / 4) * 32;
+  const float inv = 1.f / (float)pts;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int p = idx & 31;
+    const size_t r = idx >> 5;
+    const int f4 = r % (F / 4);
+    const size_t tt = r / (F / 4);
+    const int tile = tt % tiles;
+    const size_t task = tt / tiles;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tile * 32 + p < pts) v = *(const f32x4*)(d_out + task * F + 4 * f4) * inv;
+    if (accumulate) v += *(const f32x4*)(dR + idx * 4);
+    *(f32x4*)(dR + idx * 4) = v;
+  }
+}
+
+static unsigned grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  if (g > 256u * 8u) g = 256u * 8u;  // grid-stride the rest (cdna guide, Guideline 11)
+  if (g == 0) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace npf
+
+extern "C" int npf_pack_pt(const float* rows, int32_t n_tasks, int32_t pts, int32_t Fv, float* pt, void* stream) {
+  if (!rows || !pt || n_tasks <= 0 || pts <= 0 || Fv <= 0) return NPF_EINVAL;
+  const int Fp = npf::round_up(Fv, 32);
+  const size_t total = (size_t)n_tasks * ((pts + 31) / 32) * (Fp / 4) * 32;
+  hipLaunchKernelGGL(npf::pack_pt_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_tasks,
+                     pts, Fv, Fp, pt);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_unpack_pt(const float* pt, int32_t n_tasks, int32_t pts, int32_t Fv, float* rows, void* stream) {
+  if (!rows || !pt || n_tasks <= 0 || pts <= 0 || Fv <= 0) return NPF_EINVAL;
+  const int Fp = npf::round_up(Fv, 32);
+  const size_t total = (size_t)n_tasks * ((pts + 31) / 32) * (Fp / 4) * 32;
+  hipLaunchKernelGGL(npf::unpack_pt_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pt,
+                     n_tasks, pts, Fv, Fp, rows);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_transpose(const float* src, int32_t rows, int32_t cols, float* dst, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return NPF_EINVAL;
+  hipLaunchKernelGGL(npf::transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     src, rows, cols, dst);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_mean_agg_fwd(const float* R_pt, int32_t n_tasks, int32_t pts, int32_t F, float* out, void* stream) {
+  if (!R_pt || !out || n_tasks <= 0 || pts <= 0 || F <= 0 || (F & 31)) return NPF_EINVAL;
+  hipLaunchKernelGGL(npf::mean_agg_fwd_kernel, dim3(F / 32, n_tasks), dim3(256), 0, (hipStream_t)stream, R_pt, pts, F, out);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_mean_agg_bwd(const float* d_out, int32_t n_tasks, int32_t pts, int32_t F, float* dR_pt,
+                                int32_t accumulate, void* stream) {
+  if (!d_out || !dR_pt || n_tasks <= 0 || pts <= 0 || F <= 0 || (F & 31)) return NPF_EINVAL;
+  const size_t total = (size_t)n_tasks * ((pts + 31) / 32) * (F / 4) * 32;
+  hipLaunchKernelGGL(npf::mean_agg_bwd_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, d_out,
+                     n_tasks, pts, F, dR_pt, accumulate);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_version(void) { return 1; }

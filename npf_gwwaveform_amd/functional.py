@@ -1,0 +1,138 @@
+"""Autograd wrappers of the non-chain kernels: layout changes, mean aggregation over the
+points of a task, and the Gaussian head.  Every function launches HIP kernels through the
+C ABI (``_lib``); none has a CPU path."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .chain import pad32, pt_empty, tiles_of
+
+
+# ---- layout ---------------------------------------------------------------------------
+def _pack(rows: torch.Tensor) -> torch.Tensor:
+    n_tasks, pts, F = rows.shape
+    out = pt_empty(n_tasks, pts, F, rows.device)
+    L.check(L.load().npf_pack_pt(L.ptr(rows.contiguous()), n_tasks, pts, F, L.ptr(out), L.stream_ptr()), "npf_pack_pt")
+    return out
+
+
+def _unpack(pt: torch.Tensor, pts: int, F: int) -> torch.Tensor:
+    n_tasks = pt.shape[0]
+    out = torch.empty((n_tasks, pts, F), dtype=torch.float32, device=pt.device)
+    L.check(L.load().npf_unpack_pt(L.ptr(pt.contiguous()), n_tasks, pts, F, L.ptr(out), L.stream_ptr()), "npf_unpack_pt")
+    return out
+
+
+class _PackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows):
+        ctx.pts, ctx.F = rows.shape[1], rows.shape[2]
+        return _pack(rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _unpack(g.contiguous(), ctx.pts, ctx.F)
+
+
+class _UnpackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pt, pts, F):
+        return _unpack(pt, pts, F)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _pack(g.contiguous()), None, None
+
+
+def pack_pt(rows: torch.Tensor) -> torch.Tensor:
+    """row-major [n_tasks, pts, F] -> PT32 (padding points / features are zero)."""
+    return _PackFn.apply(rows)
+
+
+def unpack_pt(pt: torch.Tensor, pts: int, F: int) -> torch.Tensor:
+    """PT32 -> row-major [n_tasks, pts, F]."""
+    return _UnpackFn.apply(pt, pts, F)
+
+
+# ---- mean over the points of a task ---------------------------------------------------
+def sum_points_pt(pt: torch.Tensor, pts: int, F: int) -> torch.Tensor:
+    """[n_tasks, pad32(F)] sum over the valid points (no autograd)."""
+    n_tasks = pt.shape[0]
+    Fp = pad32(F)
+    out = torch.empty((n_tasks, Fp), dtype=torch.float32, device=pt.device)
+    L.check(L.load().npf_mean_agg_fwd(L.ptr(pt), n_tasks, pts, Fp, L.ptr(out), L.stream_ptr()), "npf_mean_agg_fwd")
+    return out * float(pts)
+
+
+class _MeanAggFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pt, pts, F):
+        n_tasks, Fp = pt.shape[0], pad32(F)
+        ctx.geo = (n_tasks, pts, Fp)
+        out = torch.empty((n_tasks, Fp), dtype=torch.float32, device=pt.device)
+        L.check(L.load().npf_mean_agg_fwd(L.ptr(pt.contiguous()), n_tasks, pts, Fp, L.ptr(out), L.stream_ptr()),
+                "npf_mean_agg_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n_tasks, pts, Fp = ctx.geo
+        d = pt_empty(n_tasks, pts, Fp, g.device)
+        L.check(L.load().npf_mean_agg_bwd(L.ptr(g.contiguous()), n_tasks, pts, Fp, L.ptr(d), 0, L.stream_ptr()),
+                "npf_mean_agg_bwd")
+        return d, None, None
+
+
+def mean_agg(pt: torch.Tensor, pts: int, F: int) -> torch.Tensor:
+    """torch.mean(R, dim=1) of a PT32 tensor -> row-major [n_tasks, pad32(F)]
+    (npf/neuralproc/np.py:95, attnnp.py:181)."""
+    return _MeanAggFn.apply(pt, pts, F)
+
+
+# ---- Gaussian head --------------------------------------------------------------------
+class _GaussHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, suff, Y, dy, homosk):
+        n_rows, pts, two_dy = suff.shape
+        assert two_dy == 2 * dy
+        suff = suff.contiguous()
+        loc = torch.empty((n_rows, pts, dy), dtype=torch.float32, device=suff.device)
+        scale = torch.empty_like(loc)
+        slp = None
+        n_y = 0
+        if Y is not None:
+            Y = Y.contiguous()
+            n_y = Y.shape[0]
+            assert Y.shape[1:] == (pts, dy) and n_rows % n_y == 0
+            slp = torch.empty((n_rows,), dtype=torch.float32, device=suff.device)
+        L.check(L.load().npf_gauss_head_fwd(L.ptr(suff), n_rows, pts, dy, int(homosk), L.ptr(Y), n_y, L.ptr(loc),
+                                            L.ptr(scale), L.ptr(slp), L.stream_ptr()), "npf_gauss_head_fwd")
+        ctx.save_for_backward(suff, loc, scale, Y)
+        ctx.cfg = (dy, homosk)
+        if slp is None:
+            slp = torch.zeros((n_rows,), dtype=torch.float32, device=suff.device)
+            ctx.mark_non_differentiable(slp)
+        return loc, scale, slp
+
+    @staticmethod
+    def backward(ctx, d_loc, d_scale, d_slp):
+        suff, loc, scale, Y = ctx.saved_tensors
+        dy, homosk = ctx.cfg
+        n_rows, pts, _ = suff.shape
+        d_suff = torch.empty_like(suff)
+        c = lambda t: t.contiguous() if t is not None else None  # noqa: E731
+        L.check(L.load().npf_gauss_head_bwd(L.ptr(suff), L.ptr(loc), L.ptr(scale), n_rows, pts, dy, int(homosk),
+                                            L.ptr(Y), Y.shape[0] if Y is not None else 0, L.ptr(c(d_loc)),
+                                            L.ptr(c(d_scale)), L.ptr(c(d_slp)) if Y is not None else None,
+                                            L.ptr(d_suff), L.stream_ptr()), "npf_gauss_head_bwd")
+        return d_suff, None, None, None
+
+
+def gauss_head(suff: torch.Tensor, Y: Optional[torch.Tensor], dy: int, homoskedastic: bool):
+    """(loc, scale, sum_log_prob) from the raw decoder output ``suff`` [rows, pts, 2*dy]
+    (npf/neuralproc/base.py:350-365; losses.py:18-24).  ``sum_log_prob`` [rows] is the
+    log-likelihood of ``Y`` [rows or B, pts, dy] summed over targets and y-dims."""
+    return _GaussHeadFn.apply(suff, Y, dy, homoskedastic)

@@ -1,0 +1,216 @@
+"""GPU parity tests of the individual HIP kernels, through the C ABI (ctypes), against the
+stage-level golden vectors of the reference (tests/golden/g6_stages.npz) and plain fp32
+torch on the CPU.  Tolerance (fp32): max|d| <= 1e-5 * max|ref| per tensor."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import specs
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _mods():
+    from npf_gwwaveform_amd import chain as CH
+    from npf_gwwaveform_amd import functional as FN
+    return CH, FN
+
+
+def assert_close(got, ref, tol=1e-5, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    m = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max()
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    assert err <= tol * m, f"{what}: max|d|={err:.3e} > {tol:.0e} * max|ref|={m:.3e}"
+
+
+def to_pt_ref(rows: torch.Tensor) -> torch.Tensor:
+    """Pure-index statement of the PT32 layout (include/npf_hip.h)."""
+    n_tasks, pts, F = rows.shape
+    tiles, Fp = (pts + 31) // 32, (F + 31) // 32 * 32
+    buf = torch.zeros(n_tasks, tiles * 32, Fp)
+    buf[:, :pts, :F] = rows
+    return buf.view(n_tasks, tiles, 32, Fp // 4, 4).permute(0, 1, 3, 2, 4).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(3, 70, 64), (1, 32, 32), (2, 5, 2), (4, 129, 100), (2, 256, 256)])
+def test_pack_unpack(shape):
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(0)
+    rows = torch.randn(*shape, generator=g)
+    pt = FN.pack_pt(rows.to(DEV))
+    assert tuple(pt.shape) == CH.pt_shape(*shape)
+    assert torch.equal(pt.cpu(), to_pt_ref(rows))
+    back = FN.unpack_pt(pt, shape[1], shape[2])
+    assert torch.equal(back.cpu(), rows)
+
+
+@pytest.mark.parametrize("K,N", [(64, 64), (256, 256), (32, 256), (256, 4), (96, 48), (128, 256), (40, 17), (256, 32)])
+@pytest.mark.parametrize("per_task", [False, True])
+def test_single_linear(K, N, per_task):
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(K * 1000 + N)
+    n_tasks, pts = 3, 70
+    x = torch.randn(n_tasks, pts, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    ref = torch.relu(torch.nn.functional.linear(x, W, b))
+    ch = CH.Chain(n_tasks, pts, DEV, wg_per_task=per_task)
+    ch.input_pt(FN.pack_pt(x.to(DEV)), K).linear(W.to(DEV), b.to(DEV), relu=True).output_pt()
+    (y_pt,) = ch.run()
+    y = FN.unpack_pt(y_pt, pts, N)
+    assert_close(y, ref, what=f"linear {K}->{N}")
+    # padding features of the PT output must be exactly zero (they feed later layers)
+    full = FN.unpack_pt(y_pt, pts, CH.pad32(N)).cpu()
+    assert torch.count_nonzero(full[..., N:]) == 0
+
+
+def test_rows_io_and_no_bias():
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(5)
+    n_tasks, pts = 2, 45
+    x = torch.rand(n_tasks, pts, 2, generator=g) * 2 - 1
+    W0, W1 = torch.randn(32, 2, generator=g), torch.randn(4, 32, generator=g)
+    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, W0)), W1)
+    ch = CH.Chain(n_tasks, pts, DEV)
+    ch.input_rows(x.to(DEV), 2).linear(W0.to(DEV), None, relu=True).linear(W1.to(DEV), None).output_rows()
+    (y,) = ch.run()
+    assert_close(y, ref, what="rows io")
+
+
+def _mlp_params(g, tag):
+    pre = f"mlp_{tag}/param/"
+    return {k[len(pre):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre)}
+
+
+def _layers(params):
+    names = ["to_hidden"]
+    i = 0
+    while f"linears.{i}.weight" in params:
+        names.append(f"linears.{i}")
+        i += 1
+    names.append("out")
+    return names
+
+
+@pytest.mark.parametrize("tag", ["sq", "clamp", "skinny", "wide"])
+def test_mlp_chain_fwd_bwd_vs_reference_fixture(tag):
+    """MLP.forward + autograd (npf/architectures/mlp.py:95-109) on the reference's vectors."""
+    CH, FN = _mods()
+    g = specs.load_golden("g6_stages")
+    params = {k: v.to(DEV).requires_grad_() for k, v in _mlp_params(g, tag).items()}
+    x = torch.from_numpy(g[f"mlp_{tag}/x"]).to(DEV).requires_grad_()
+    rows, n_in = x.shape
+    names = _layers(params)
+    ch = CH.Chain(1, rows, DEV)
+    ch.input_pt(FN.pack_pt(x.view(1, rows, n_in)), n_in)
+    for j, nm in enumerate(names):
+        ch.linear(params[f"{nm}.weight"], params[f"{nm}.bias"], relu=(j < len(names) - 1))
+    ch.output_pt()
+    (y_pt,) = ch.run()
+    n_out = params["out.weight"].shape[0]
+    y = FN.unpack_pt(y_pt, rows, n_out).view(rows, n_out)
+    assert_close(y, g[f"mlp_{tag}/y"], what=f"mlp {tag} y")
+    (y * torch.from_numpy(g[f"mlp_{tag}/w"]).to(DEV)).sum().backward()
+    assert_close(x.grad, g[f"mlp_{tag}/dx"], what=f"mlp {tag} dx")
+    for k, p in params.items():
+        assert_close(p.grad, g[f"mlp_{tag}/grad/{k}"], what=f"mlp {tag} d{k}")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_scaledot_attention_fwd_bwd_vs_reference_fixture(tag):
+    """DotAttender (npf/architectures/attention.py:129-164,204-220) on the reference's vectors."""
+    CH, FN = _mods()
+    g = specs.load_golden("g6_stages")
+    k = torch.from_numpy(g[f"attn_{tag}/keys"]).to(DEV).requires_grad_()
+    q = torch.from_numpy(g[f"attn_{tag}/queries"]).to(DEV).requires_grad_()
+    v = torch.from_numpy(g[f"attn_{tag}/values"]).to(DEV).requires_grad_()
+    B, C, d = k.shape
+    T, r = q.shape[1], v.shape[2]
+    ch = CH.Chain(B, T, DEV, wg_per_task=True)
+    ch.input_pt(FN.pack_pt(q), d).attn_scores(FN.pack_pt(k), C).softmax(1.0 / math.sqrt(d)).attn_values(FN.pack_pt(v), r)
+    ch.output_pt()
+    (o_pt,) = ch.run()
+    o = FN.unpack_pt(o_pt, T, r)
+    assert_close(o, g[f"attn_{tag}/out"], what=f"attn {tag} out")
+    (o * torch.from_numpy(g[f"attn_{tag}/w"]).to(DEV)).sum().backward()
+    assert_close(q.grad, g[f"attn_{tag}/dqueries"], what=f"attn {tag} dq")
+    assert_close(k.grad, g[f"attn_{tag}/dkeys"], what=f"attn {tag} dk")
+    assert_close(v.grad, g[f"attn_{tag}/dvalues"], what=f"attn {tag} dv")
+
+
+def test_merge_addend_and_taskvec():
+    """relu(x1 + resizer(x2)) with a PT addend (encoders.py:175-183) and a per-task vector."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(11)
+    n_tasks, pts, r = 3, 50, 64
+    x1 = torch.randn(n_tasks, pts, r, generator=g).requires_grad_()
+    x2 = torch.randn(n_tasks, pts, r, generator=g).requires_grad_()
+    vec = torch.randn(n_tasks, r, generator=g).requires_grad_()
+    W = (torch.randn(r, r, generator=g) / 8).requires_grad_()
+    b = (torch.randn(r, generator=g) * 0.1).requires_grad_()
+    w_out = torch.randn(n_tasks, pts, r, generator=g)
+    ref = torch.relu(torch.relu(x1 + torch.nn.functional.linear(x2, W, b)) + vec[:, None, :])
+    (ref * w_out).sum().backward()
+    refs = [t.grad.clone() for t in (x1, x2, vec, W, b)]
+    d = [t.detach().to(DEV).requires_grad_() for t in (x1, x2, vec, W, b)]
+    ch = CH.Chain(n_tasks, pts, DEV)
+    ch.input_pt(FN.pack_pt(d[1]), r).linear(d[3], d[4], relu=True, addend=FN.pack_pt(d[0])).add_taskvec(d[2], relu=True)
+    ch.output_pt()
+    (y_pt,) = ch.run()
+    y = FN.unpack_pt(y_pt, pts, r)
+    assert_close(y, ref, what="merge fwd")
+    (y * w_out.to(DEV)).sum().backward()
+    for name, t, rf in zip(("x1", "x2", "vec", "W", "b"), d, refs):
+        assert_close(t.grad, rf, what=f"merge d{name}")
+
+
+@pytest.mark.parametrize("homosk", [False, True])
+@pytest.mark.parametrize("dy", [1, 2, 3])
+def test_gauss_head(homosk, dy):
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(3)
+    rows, B, pts = 6, 3, 77
+    suff = torch.randn(rows, pts, 2 * dy, generator=g).requires_grad_()
+    suff.data[0, 0, dy] = 25.0  # softplus threshold branch
+    Y = torch.randn(B, pts, dy, generator=g)
+    loc, raw = suff.split(dy, dim=-1)
+    scale = 0.01 + 0.99 * torch.nn.functional.softplus(raw)
+    if homosk:
+        scale = scale.mean(1, keepdim=True).expand(rows, pts, dy)
+    dist = torch.distributions.Independent(torch.distributions.Normal(loc, scale), 1)
+    slp = dist.log_prob(Y.repeat(rows // B, 1, 1)).sum(-1)
+    wl, ws, wp = (torch.randn(*s, generator=g) for s in (loc.shape, scale.shape, slp.shape))
+    ((loc * wl).sum() + (scale * ws).sum() + (slp * wp).sum()).backward()
+    s2 = suff.detach().to(DEV).requires_grad_()
+    loc2, scale2, slp2 = FN.gauss_head(s2, Y.to(DEV), dy, homosk)
+    assert_close(loc2, loc, what="loc")
+    assert_close(scale2, scale, what="scale")
+    assert_close(slp2, slp, what="sum_logp")
+    ((loc2 * wl.to(DEV)).sum() + (scale2 * ws.to(DEV)).sum() + (slp2 * wp.to(DEV)).sum()).backward()
+    assert_close(s2.grad, suff.grad, tol=2e-5, what="d_suff")
+
+
+def test_mean_agg():
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5, 41, 64, generator=g).requires_grad_()
+    w = torch.randn(5, 64, generator=g)
+    (x.mean(1) * w).sum().backward()
+    x2 = x.detach().to(DEV).requires_grad_()
+    m = FN.mean_agg(FN.pack_pt(x2), 41, 64)
+    assert_close(m, x.mean(1), what="mean")
+    (m * w.to(DEV)).sum().backward()
+    assert_close(x2.grad, x.grad, what="dmean")
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    CH, FN = _mods()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FN.pack_pt(torch.zeros(1, 4, 4))
