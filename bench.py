@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the neural-process train step on MI355X (see DESIGN.md section "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = forward + loss + backward + (N > 1: bucketed RCCL gradient all-reduce) + Adam on one
+synthetic batch of the BASELINE.json config-2 workload: AttnCNP (scaledot), r = 256, 4-layer
+xy-encoder / decoder, 256 context and 1024 target frequency points, 256 tasks PER GPU, fp32
+(weak scaling).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line.  For N > 1 launch with ``python -m torch.distributed.run --nproc-per-node N``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+from functools import partial
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_16x16x4_f32) = vector peak
+FLOP_PER_PT_TRAIN = {"attncnp": 4_148_544, "attnlnp": 6_952_768}  # SURVEY.md 8d (FlopCounterMode on the reference)
+
+
+def build_model(kind: str, r: int, L: int, device):
+    import npf_gwwaveform_amd as A
+
+    torch.manual_seed(0)
+    kw = dict(r_dim=r,
+              XYEncoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, is_force_hid_smaller=True, hidden_size=r),
+                                           is_sum_merge=True),
+              Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, hidden_size=r), is_sum_merge=True))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if kind == "attncnp":
+            m, crit = A.AttnCNP(1, 2, attention="scaledot", **kw), A.CNPFLoss()
+        else:
+            m = A.AttnLNP(1, 2, attention="scaledot", is_q_zCct=True, n_z_samples_train=1, n_z_samples_test=1, **kw)
+            crit = A.ELBOLossLNPF()
+    return m.to(device), crit
+
+
+def cpu_baseline(kind: str, r: int, L: int, C: int, T: int, budget_s: float = 12.0):
+    """The oracle (CPU restatement of the reference, oracle/npf_oracle.py) on the host cores:
+    the same train step (forward, loss, backward, Adam lr 1e-3) at the same shapes, on a
+    bounded sample (small batch, a few steps)."""
+    from oracle import npf_oracle as O
+    from npf_gwwaveform_amd.train import synthetic_waveform_batch
+
+    avail = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # a 1-GPU box's CPU share is 16 cores (more threads than that oversubscribe the host)
+    cores = max(1, min(avail, int(os.environ.get("NPF_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    B = 8
+    cfg = O.OracleConfig(kind="AttnCNP" if kind == "attncnp" else "AttnLNP", x_dim=1, y_dim=2, r_dim=r,
+                         is_q_zCct=(kind != "attncnp"))
+    params = {k: v.clone().requires_grad_(True) for k, v in O.init_params(cfg, 0, L, L).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    batch = synthetic_waveform_batch(B, C, T, 99, "cpu")
+    eps = torch.randn(1, B, 1, r) if kind != "attncnp" else None
+    loss_fn = O.cnpf_loss if kind == "attncnp" else O.elbo_loss
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = O.forward(cfg, params, batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"], eps=eps)
+        loss_fn(out, batch["Y_trgt"]).backward()
+        opt.step()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {"value": B * T * n / el, "unit": "target-points/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps (fwd+loss+bwd+Adam) of the CPU oracle at the same shapes with batch {B} "
+                      f"(C={C}, T={T}, r={r}, L={L}), {el:.1f} s, torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="attncnp", choices=["attncnp", "attnlnp"])
+    ap.add_argument("--batch", type=int, default=256, help="tasks per GPU")
+    ap.add_argument("--ctx", type=int, default=256)
+    ap.add_argument("--trgt", type=int, default=1024)
+    ap.add_argument("--r", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from npf_gwwaveform_amd import chain as CH
+    from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
+
+    B, C, T = args.batch, args.ctx, args.trgt
+    model, crit = build_model(args.model, args.r, args.layers, dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    trainer = Trainer(model, crit, lr=1e-3, world=world)
+    batches = [synthetic_waveform_batch(B, C, T, 1234 + rank * 10**6 + i, dev) for i in range(4)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.step(batches[i % len(batches)])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * T * args.steps / elapsed
+    loss_val = float(loss.item())
+
+    roofline = None
+    kernels = {}
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass: HIP events around every kernel launch on the launch stream
+        CH.PROFILE = []
+        n_prof = 3
+        for i in range(n_prof):
+            trainer.step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in CH.PROFILE:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        CH.PROFILE = None
+        for name, (n, fl, sec) in agg.items():
+            kernels[name] = {"launches_per_step": n / n_prof, "avg_launch_ms": sec / n * 1e3,
+                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12}
+        dom = max(agg.items(), key=lambda kv: kv[1][2])
+        name, (n, fl, sec) = dom
+        ach = fl / sec * 1e-12
+        roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
+    elif world > 1 and not args.no_roofline:
+        pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.r, args.layers, C, T)
+
+    if rank == 0:
+        flop_pt = FLOP_PER_PT_TRAIN[args.model] if (args.r, args.layers, C, T) == (256, 4, 256, 1024) else None
+        line = {
+            "metric": "waveform target-points/sec (train step)",
+            "value": value,
+            "unit": "target-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 2: {'AttnCNP' if args.model == 'attncnp' else 'AttnLNP(is_q_zCct, n_z=1)'} "
+                            f"scaledot, r={args.r}, {args.layers}-layer xy-encoder/decoder, {C} context / {T} target "
+                            f"points, {B} tasks per GPU, fp32 train step (fwd+loss+bwd+allreduce+Adam)",
+                "tasks_per_gpu": B, "global_tasks": B * world, "context_points": C, "target_points": T,
+                "r_dim": args.r, "n_params": n_params, "parallelism": f"dp{world}", "final_loss": loss_val,
+                "train_step_tflops_algorithmic": (value * flop_pt * 1e-12) if flop_pt else None,
+                "kernels": kernels,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

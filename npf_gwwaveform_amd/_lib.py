@@ -108,13 +108,13 @@ def stream_ptr(device: Optional[torch.device] = None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+def ptr(t: Optional[torch.Tensor], strided: bool = False) -> Optional[int]:
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("the HIP path takes device tensors only (got a CPU tensor); there is no CPU fallback")
     if t.dtype != torch.float32:
         raise RuntimeError(f"the HIP path computes in fp32 (got {t.dtype})")
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise RuntimeError("tensor handed to the HIP path must be contiguous")
     return t.data_ptr()

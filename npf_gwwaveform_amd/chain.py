@@ -21,6 +21,11 @@ import torch
 from . import _lib as L
 
 
+# bench.py sets this to a list to time every launch with HIP events on the launch stream:
+# entries are (kernel, algorithmic flops, start event, end event)
+PROFILE = None
+
+
 def pad32(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -96,12 +101,27 @@ class Program:
                w_tiles=0, w_task_stride=0, b_task_stride=0):
         flags = (L.F_RELU if relu else 0) | (L.F_ADD_PT if addend is not None else 0)
         i3 = (ldw if ldw is not None else K) if mode == L.W_ROWMAJOR else w_tiles
-        self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=mode, i3=i3, flags=flags, i4=addend_modulus, p0=self._p(W),
+        self.keep.append(W)
+        self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=mode, i3=i3, flags=flags, i4=addend_modulus, p0=L.ptr(W, strided=True),
                  p1=self._p(bias), p2=self._p(addend), s0=w_task_stride, s1=b_task_stride)
+
+    def flops(self) -> int:
+        """Algorithmic GEMM FLOPs of one launch: 2*K*N per LINEAR per valid point."""
+        return sum(2 * o.i0 * o.i1 for o in self.ops if o.op == L.OP_LINEAR) * self.n_tasks * self.pts
 
     def launch(self) -> None:
         if not self.ops:
             return
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            self._launch()
+            ev1.record()
+            PROFILE.append(("chain_kernel", self.flops(), ev0, ev1))
+        else:
+            self._launch()
+
+    def _launch(self) -> None:
         prog = L.NpfProgram()
         prog.n_ops = len(self.ops)
         prog.n_tasks, prog.pts_per_task, prog.tiles_per_task = self.n_tasks, self.pts, tiles_of(self.pts)
@@ -115,6 +135,17 @@ def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
     """jobs: dicts(dZ, A, N, K, dW, db=None, ldw=None, per_task=False, accumulate=False)."""
     if not jobs:
         return
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        _run_wgrad(jobs, n_tasks, pts, device)
+        ev1.record()
+        PROFILE.append(("wgrad_kernel", sum(2 * j["N"] * j["K"] for j in jobs) * n_tasks * pts, ev0, ev1))
+    else:
+        _run_wgrad(jobs, n_tasks, pts, device)
+
+
+def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
     lib = L.load()
     for i0 in range(0, len(jobs), L.NPF_MAX_WGRAD_JOBS):
         chunk = jobs[i0:i0 + L.NPF_MAX_WGRAD_JOBS]
@@ -185,15 +216,22 @@ class Chain:
 
     # ---- layers
     def linear(self, W: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
-               addend: Optional[torch.Tensor] = None, addend_modulus: int = 0) -> "Chain":
+               addend: Optional[torch.Tensor] = None, addend_modulus: int = 0,
+               bias_per_task: bool = False) -> "Chain":
+        """cur <- act(W cur + b [+ addend]).  ``W`` [N, K] may be a column slice of a wider
+        matrix (row stride = ``W.stride(0)``); ``bias_per_task``: ``b`` is [n_tasks, pad32(N)]."""
         N, K = W.shape
         if K != self.F:
             raise ValueError(f"Linear expects {K} inputs, chain carries {self.F}")
         if max(N, K) > L.NPF_MAX_FEATURES:
             raise NotImplementedError(
                 f"layer {K}->{N}: the HIP chain keeps at most {L.NPF_MAX_FEATURES} features in registers")
+        if W.stride(1) != 1:
+            raise ValueError("weight rows must be contiguous")
+        if bias_per_task and not self.wg_per_task:
+            raise ValueError("per-task biases need wg_per_task=True")
         self.steps.append(_Step("linear", {"W": self._t(W), "b": self._t(b), "add": self._t(addend)},
-                                {"N": N, "K": K, "relu": relu, "mod": addend_modulus}))
+                                {"N": N, "K": K, "relu": relu, "mod": addend_modulus, "bpt": bias_per_task}))
         self.F = N
         return self
 
@@ -289,7 +327,8 @@ class _ChainFn(torch.autograd.Function):
                 if train and (needs_grad[W] or (b >= 0 and needs_grad[b])):
                     saved[(i, "in")] = ensure_saved(a["K"])
                 prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
-                            addend=T[add] if add >= 0 else None, addend_modulus=a["mod"])
+                            addend=T[add] if add >= 0 else None, addend_modulus=a["mod"], ldw=T[W].stride(0),
+                            b_task_stride=(T[b].stride(0) if a["bpt"] else 0))
                 backed = None
                 upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if train and a["relu"] and upstream:
@@ -394,12 +433,14 @@ class _ChainFn(torch.autograd.Function):
                     dz = new_pt(a["N"])
                     prog.store_pt(dz, a["N"])
                     if needs_grad[W] or (b >= 0 and needs_grad[b]):
-                        dW = torch.empty_like(T[W])
-                        db = torch.empty_like(T[b]) if b >= 0 else None
+                        dW = torch.empty((a["N"], a["K"]), dtype=torch.float32, device=dev)
+                        db = torch.empty((a["N"],), dtype=torch.float32, device=dev) if (b >= 0 and not a["bpt"]) else None
                         jobs.append(dict(dZ=dz, A=saved[(i, "in")], N=a["N"], K=a["K"], dW=dW, db=db))
                         grads[W] = dW
-                        if b >= 0:
+                        if b >= 0 and not a["bpt"]:
                             grads[b] = db
+                    if b >= 0 and a["bpt"] and needs_grad[b]:
+                        pending_taskvec.append((b, dz, a["N"], 0))
                     if add >= 0 and needs_grad[add]:
                         grads[add] = (dz, a["mod"])  # resolved after the launch
                 if upstream_before[i]:

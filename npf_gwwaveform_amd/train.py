@@ -1,0 +1,64 @@
+"""Minimal optimisation step of the path and the synthetic waveform batches it is timed on.
+
+The reference trains through skorch (utils/train.py:260-263; ``get_loss`` :342-349): per
+batch ``module.train(); out = module(**batch); loss = criterion(out, Y_trgt);
+loss.backward(); Adam(lr=1e-3).step()``.  ``Trainer.step`` is that sequence with the
+data-parallel gradient all-reduce in front of the optimizer.
+Host code (Adam, all-reduce, control flow) is PyTorch, as the north star prescribes.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .parallel import BucketedGradReducer, FlatParameters
+
+
+def synthetic_waveform_batch(B: int, C: int, T: int, seed: int, device, dx: int = 1, dy: int = 2, n_z_eps: int = 0,
+                             z_dim: int = 0):
+    """Random-source-parameter, random-frequency-grid batch: per task a smooth
+    inspiral-like amplitude/phase pair on ``C + T`` sorted random frequencies in [-1, 1];
+    a random subset of C points is the context, the other T are the targets.  Generated on
+    the device; throughput does not depend on the values."""
+    assert dx == 1 and dy == 2
+    g = torch.Generator(device=device).manual_seed(seed)
+    N = C + T
+    theta = torch.rand(B, 4, generator=g, device=device)
+    f, _ = torch.sort(torch.rand(B, N, generator=g, device=device) * 2 - 1, dim=1)
+    ft = 1.5 + f / 2  # in [1, 2]
+    amp = ft.pow(-7.0 / 6.0) * (1 + 0.5 * theta[:, 0:1])
+    phase = theta[:, 3:4] + theta[:, 0:1] * ft.pow(-5.0 / 3.0) + theta[:, 1:2] / ft + theta[:, 2:3] * ft
+    phase = (phase - phase.mean()) / phase.std()
+    amp = (amp - amp.mean()) / amp.std()
+    Y = torch.stack([amp, phase], dim=-1)
+    X = f.unsqueeze(-1)
+    perm = torch.argsort(torch.rand(B, N, generator=g, device=device), dim=1)
+    ci, ti = perm[:, :C], perm[:, C:]
+    take = lambda t, idx: torch.gather(t, 1, idx.unsqueeze(-1).expand(-1, -1, t.shape[-1])).contiguous()  # noqa: E731
+    return dict(X_cntxt=take(X, ci), Y_cntxt=take(Y, ci), X_trgt=take(X, ti), Y_trgt=take(Y, ti))
+
+
+class Trainer:
+    """forward -> loss -> backward -> (bucketed all-reduce) -> Adam, on flat parameter /
+    gradient buffers."""
+
+    def __init__(self, model: torch.nn.Module, criterion: torch.nn.Module, lr: float = 1e-3, world: Optional[int] = None,
+                 bucket_bytes: int = 2 << 20):
+        self.model, self.criterion = model, criterion
+        self.flat = FlatParameters(model.parameters())
+        self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
+        self.opt = torch.optim.Adam([self.flat.flat], lr=lr)
+        self.model.train()
+        self.criterion.train()
+
+    def step(self, batch: dict) -> torch.Tensor:
+        for p in self.flat.params:
+            p.grad = None
+        self.reducer.reset()
+        out = self.model(batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"])
+        loss = self.criterion(out, batch["Y_trgt"])
+        loss.backward()
+        self.flat.flat.grad = self.reducer.finish()
+        self.opt.step()
+        return loss.detach()

@@ -1,0 +1,135 @@
+"""GPU parity of the full models (forward, loss, backward) against the golden vectors the
+reference produced (tests/golden/*.npz) -- through this package's drop-in classes, i.e.
+through the C ABI.  Tolerances (fp32): loc/scale max|d| <= 1e-5 max|ref| and
+sigma element-wise rel <= 1e-5; gradients max|d| <= 1e-4 max|ref| (they are sums of up to
+2.6e5 fp32 terms whose order differs from the CPU BLAS)."""
+import numpy as np
+import pytest
+import torch
+
+import specs
+from helpers import EpsIndependent, assert_close, build_loss, build_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(case, train=True):
+    model = build_model(case, DEV)
+    inp = {k: v.to(DEV) for k, v in specs.make_inputs(case).items()}
+    if "eps" in inp:
+        EpsIndependent.eps = inp["eps"]
+    crit = build_loss(case)
+    model.train(train)
+    crit.train(train)
+    if train:
+        out = model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+        loss = crit(out, inp["Y_trgt"])
+        loss.backward()
+    else:
+        with torch.no_grad():
+            out = model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"])
+        loss = None
+    return model, out, loss
+
+
+@pytest.mark.parametrize("name", list(specs.CASES))
+def test_model_train_step_parity(name):
+    case = specs.CASES[name]
+    g = specs.load_golden(name)
+    model, out, loss = _run(case)
+    p_yCc, z_samples, q_zCc, q_zCct = out
+    assert_close(p_yCc.base_dist.loc, g["loc"], what="loc")
+    assert_close(p_yCc.base_dist.scale, g["scale"], what="scale")
+    np.testing.assert_allclose(p_yCc.base_dist.scale.detach().cpu().numpy(), g["scale"], rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=2e-5)
+    if "z_samples" in g:
+        assert_close(z_samples, g["z_samples"], what="z_samples")
+        assert_close(q_zCc.base_dist.loc, g["q_zCc_loc"], what="q_zCc.loc")
+        assert_close(q_zCc.base_dist.scale, g["q_zCc_scale"], what="q_zCc.scale")
+    if "q_zCct_loc" in g:
+        assert_close(q_zCct.base_dist.loc, g["q_zCct_loc"], what="q_zCct.loc")
+    full = f"grad/x_encoder.out.weight" in g
+    for k, p in model.named_parameters():
+        grad = p.grad if p.grad is not None else torch.zeros_like(p)
+        if full:
+            assert_close(grad, g[f"grad/{k}"], tol=1e-4, what=f"grad {k}")
+        else:
+            n_ref = float(g[f"gradnorm/{k}"])
+            assert abs(grad.double().norm().item() - n_ref) <= 1e-4 * max(n_ref, 1e-12), k
+            head = g[f"gradhead/{k}"]
+            np.testing.assert_allclose(grad.reshape(-1)[:64].cpu().numpy(), head, rtol=1e-3,
+                                       atol=1e-4 * np.abs(head).max() + 1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["g1_cnp_c1", "g2_lnp_both_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64", "g6_cnp_homosk",
+                                  "g6_attncnp_ragged", "g3_attncnp_c2"])
+def test_model_eval_parity(name):
+    case = specs.CASES[name]
+    g = specs.load_golden(name)
+    _, out, _ = _run(case, train=False)
+    assert_close(out[0].base_dist.loc, g["eval_loc"], what="eval loc")
+    assert_close(out[0].base_dist.scale, g["eval_scale"], what="eval scale")
+
+
+def test_adam_step_matches_reference_g1():
+    case = specs.CASES["g1_cnp_c1"]
+    g = specs.load_golden("g1_cnp_c1")
+    model, _, _ = _run(case)
+    torch.optim.Adam(model.parameters(), lr=1e-3).step()
+    for k, p in model.named_parameters():
+        # Adam's first step moves every weight by lr * sign(grad): compare the moved weights
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"adam1/{k}"], rtol=1e-5, atol=2e-6, err_msg=k)
+
+
+def test_stage_api_matches_forward():
+    """x_encoder / encode_globally / trgt_dependent_representation / decode called one by
+    one (as utils/ntbks_helpers.py:485-518 does) give the same result as forward()."""
+    case = specs.CASES["g3s_attncnp_r64"]
+    g = specs.load_golden("g3s_attncnp_r64")
+    model = build_model(case, DEV).eval()
+    inp = {k: v.to(DEV) for k, v in specs.make_inputs(case).items()}
+    with torch.no_grad():
+        Xc = model.x_encoder(inp["X_cntxt"])
+        Xt = model.x_encoder(inp["X_trgt"])
+        R = model.encode_globally(Xc, inp["Y_cntxt"])
+        R_trgt = model.trgt_dependent_representation(Xc, None, R, Xt)
+        p = model.decode(Xt, R_trgt)
+    assert_close(p.base_dist.loc, g["eval_loc"], what="stage loc")
+    assert_close(p.base_dist.scale, g["eval_scale"], what="stage scale")
+
+
+def test_pretrained_cnp_checkpoint():
+    """Real weights shipped by the reference (results/pretrained/RBF_Kernel/CNP/run_0)."""
+    from functools import partial
+
+    import npf_gwwaveform_amd as A
+
+    g = specs.load_golden("g7_pretrained_cnp")
+    params = {k.split("cnp_param/")[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("cnp_param/")}
+    model = A.CNP(1, 1, r_dim=128, XYEncoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=2, hidden_size=256),
+                                                                is_sum_merge=True))
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        p, *_ = model(torch.from_numpy(g["X_cntxt"]).to(DEV), torch.from_numpy(g["Y_cntxt"]).to(DEV),
+                      torch.from_numpy(g["X_trgt"]).to(DEV))
+    assert_close(p.base_dist.loc, g["cnp_loc"], what="pretrained loc")
+    assert_close(p.base_dist.scale, g["cnp_scale"], what="pretrained scale")
+
+
+def test_out_of_range_features_raise_in_training():
+    case = specs.CASES["g1_cnp_c1"]
+    model = build_model(case, DEV).train()
+    inp = {k: v.to(DEV) for k, v in specs.make_inputs(case).items()}
+    with pytest.raises(ValueError, match=r"\[-1,1\]"):
+        model(inp["X_cntxt"] * 3, inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+
+
+def test_unknown_paths_raise_like_reference():
+    import npf_gwwaveform_amd as A
+
+    with pytest.raises(ValueError, match="Unknown encoded_path"):
+        A.CNP(1, 1, encoded_path="nope")
+    with pytest.raises(ValueError, match="Unknown attention"):
+        A.get_attender("nope", 8, 8, 8)
