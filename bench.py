@@ -157,6 +157,11 @@ def main():
             trainer.step(batches[i % len(batches)])
         torch.cuda.synchronize()
         agg = {}
+        if os.environ.get("NPF_BENCH_VERBOSE"):
+            per = len(CH.PROFILE) // n_prof
+            for name, flops, e0, e1 in CH.PROFILE[-per:]:
+                ms = e0.elapsed_time(e1)
+                print(f"  {name:14s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s", file=sys.stderr)
         for name, flops, e0, e1 in CH.PROFILE:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1

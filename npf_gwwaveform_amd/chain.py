@@ -24,6 +24,7 @@ from . import _lib as L
 # bench.py sets this to a list to time every launch with HIP events on the launch stream:
 # entries are (kernel, algorithmic flops, start event, end event)
 PROFILE = None
+DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microbench.py)
 
 
 def pad32(n: int) -> int:
@@ -126,6 +127,7 @@ class Program:
         prog.n_ops = len(self.ops)
         prog.n_tasks, prog.pts_per_task, prog.tiles_per_task = self.n_tasks, self.pts, tiles_of(self.pts)
         prog.wg_per_task = int(self.wg_per_task)
+        prog.reserved[0] = DEBUG_ABLATE
         for i, o in enumerate(self.ops):
             prog.ops[i] = o
         L.check(L.load().npf_chain_run(C.byref(prog), L.stream_ptr()), "npf_chain_run")

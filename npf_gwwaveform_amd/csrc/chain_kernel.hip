@@ -3,7 +3,7 @@
 // One wavefront owns 16 points (half a PT32 tile) and keeps their activations -- up to 256
 // features -- in registers for the whole chain, feature-major:  every layer computes
 //     Y^T[n][p] = sum_k W[n][k] X^T[k][p]
-// with v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD), A operand = rows of a 32-row
+// with v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD), A operand = rows of a 64-row
 // slab of W read from LDS, B operand = the previous layer's accumulator registers.  The
 // 16x16 accumulator layout (column = lane & 15 = point, row = 4*(lane>>4) + reg = feature)
 // is *already* the B-operand layout of the next layer once the weight slab is read with
@@ -13,33 +13,34 @@
 // Scaled-dot attention is two such layers whose weights are the task's keys / values with a
 // feature-axis softmax in between (the feature axis is in-lane plus two cross-lane swaps).
 //
-// Weights stream global -> registers -> LDS in 32-row slabs, one slab ahead of the MFMAs,
-// through a 2-slot ring; one barrier per slab (8192 MFMA cycles per SIMD at K = 256).
-// Workgroup = 8 waves (two per SIMD, <= 256 registers each) = 4 tiles = 128 points.
+// Weights stream global -> LDS by LDS-DMA (global_load_lds) in 32-row slabs, one slab ahead
+// of the MFMAs, through a 2-slot ring, one barrier per slab.  Workgroup = 4 waves (one per
+// SIMD) = 2 tiles = 64 points, TWO workgroups per CU (2 x 64 KB of LDS, 2 x 256 registers per
+// SIMD): the waves of one workgroup run in phase (they meet at every slab barrier), so the
+// per-slab scalar work, DMA issue and barrier bubbles of one workgroup are hidden by the
+// MFMAs of the other, independent one -- an 8-wave workgroup idles the matrix pipe there.
 //
 // Replaces the torch op sequences of MLP.forward (npf/architectures/mlp.py:95-109),
 // MergeFlatInputs.forward (encoders.py:175-183), BaseAttender.forward / DotAttender.score
 // (attention.py:129-164,204-220), merge_r_z (neuralproc/base.py:554-575) and their autograd.
+#include <type_traits>
+
 #include "npf_common.hpp"
 
 namespace npf {
 
-constexpr int kWaves = 8;
+constexpr int kWaves = 4;
 constexpr int kThreads = 64 * kWaves;
-constexpr int kTilesPerWG = 4;
-constexpr int kMaxB16 = NPF_MAX_FEATURES / 16;   // 16-feature blocks a wave keeps in registers
-constexpr int kMaxStride = NPF_MAX_FEATURES + 8;
-constexpr int kBiasOff = 32 * kMaxStride;        // the slab's 32 biases live behind its rows
-constexpr int kSlabFloats = kBiasOff + 32;
+constexpr int kTilesPerWG = 2;
+constexpr int kMaxB16 = NPF_MAX_FEATURES / 16;  // 16-feature blocks a wave keeps in registers
+constexpr int kSlabRows = 32;
+constexpr int kBlk = kSlabRows / 16;            // 16-row output blocks (accumulators) per slab
+constexpr int kSlabFloats = kSlabRows * NPF_MAX_FEATURES + 64;  // rows, then the 64 biases
 constexpr int kSlots = 2;
-constexpr int kStage = 4;                        // float4 per thread per slab (32 x 256 / 512 / 4)
-
-// Row stride (floats) of a slab with Kp columns: ds_read_b128 of 16 rows x 4 k-groups is
-// conflict free when the stride is 8 mod 64 floats.
-__device__ __forceinline__ int slab_stride(int Kp) { return Kp + ((Kp & 32) ? 40 : 8); }
 
 struct Wave {
-  int tid, p, g, half;     // p = lane & 15 (point / slab row), g = lane >> 4 (k group), half of the tile
+  int tid, lane, wave;     // wave is wave-uniform (readfirstlane)
+  int p, g, half;          // p = lane & 15 (point / slab row), g = lane >> 4 (k group), half of the tile
   int task, tile_in_task;  // wave-uniform
   bool valid;              // wave-uniform: this wave has a real tile
 };
@@ -56,146 +57,273 @@ __device__ __forceinline__ const float* pt_lane(const void* base, const npf_prog
   return (const float*)base + tile * (size_t)(F * 32) + (16 * w.half + w.p) * 4;
 }
 
-// ---- slab staging ------------------------------------------------------------------
+// ---- weight slabs -------------------------------------------------------------------
+// A slab = rows [nb*32, nb*32+32) of a layer's weight matrix, all Kp = roundup(K, 32)
+// columns, as a dense [32][Kp] fp32 image in LDS whose 16-byte chunks are XOR-swizzled
+// inside each row (chunk c of row r lives at chunk position c ^ (r & swz), swz = 15, or 7
+// when Kp/4 is not a multiple of 16), followed by the 32 biases of those rows.  The MFMA
+// A-operand read (16 rows x 4 k-groups per ds_read_b128) is then bank-conflict free, and --
+// because the image has no padding -- one wavefront-wide LDS-DMA (global_load_lds_dwordx4:
+// 64 lanes x 16 B = 1 KiB, linear in LDS, per-lane source address) fills 1 KiB of it straight
+// from global memory: the swizzle is applied to the *source* address (cdna guide 5.4 rule
+// 21).  No staging registers, no ds_write, and no VGPR result for hipcc to wait on: the DMA
+// stays in flight across the MFMA loop and is retired by the vmcnt(0) of the slab barrier.
+// Every load of the slab path is an LDS-DMA on purpose: a VGPR-destination load next to
+// LDS-DMA makes hipcc drain vmcnt(0) at unrelated places (cdna guide 5, trap (b)).
+// Out-of-range rows / columns are fetched from a 16-byte zero buffer.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Per-LINEAR constants of the slab stream (all wave-uniform).
+struct SlabOp {
+  const float* W;     // weights, already offset to this workgroup's task
+  const float* bias;  // nullptr if none, offset to the task
+  int K, N, Kp, cpr, swz, lcpr;  // cpr = 16-byte chunks per row, lcpr = log2(cpr) or -1
+  int mode, ldw, Fq, n_slabs;
+  bool vec16;
+  // fast path (16-byte pieces, power-of-two row length, no column padding): piece number i
+  // of a wave reads  base(slab) + i * step + lo[i & 3]
+  bool fast;
+  int lo[4];        // per-lane source offsets (floats), one per piece phase
+  int step;         // scalar source advance between a wave's consecutive pieces (floats)
+  int slab_stride;  // scalar source advance between consecutive slabs (floats)
+  int n_pw;         // pieces per wave per slab
+};
+
+__device__ __forceinline__ SlabOp make_slab_op(const npf_op_t& o, int task) {
+  SlabOp s;
+  s.K = o.i0;
+  s.N = o.i1;
+  s.mode = o.i2;
+  s.Kp = ((s.K + 31) >> 5) * 32;
+  s.cpr = s.Kp >> 2;
+  s.swz = (s.cpr & 15) ? 7 : 15;
+  s.lcpr = (s.cpr & (s.cpr - 1)) ? -1 : (31 - __builtin_clz(s.cpr));
+  s.ldw = o.i3;
+  s.Fq = ((s.N + 31) >> 5) * 8;
+  s.n_slabs = (s.N + kSlabRows - 1) / kSlabRows;
+  const float* W = (const float*)o.p0;
+  if (s.mode == NPF_W_ROWMAJOR) {
+    s.W = W + (size_t)task * o.s0;
+    s.vec16 = ((o.i3 & 3) == 0) && ((o.i0 & 3) == 0) && ((o.s0 & 3) == 0) && ((((uintptr_t)o.p0) & 15) == 0);
+  } else if (s.mode == NPF_W_PT_ROWS) {
+    s.W = W + (size_t)task * o.i3 * (size_t)(s.Kp * 32);  // + tile * Kp * 32 per 32 rows
+    s.vec16 = true;
+  } else {
+    s.W = W + (size_t)task * o.i3 * s.Fq * 128;
+    s.vec16 = false;
+  }
+  s.bias = o.p1 ? (const float*)o.p1 + (size_t)task * o.s1 : nullptr;
+  return s;
+}
+
+// Lane offsets of the fast DMA path.  Piece q = wave + 4 i covers linear chunks
+// [64 q, 64 q + 64) of the slab image: rows q*rpp .. (rpp = 64 / cpr rows per piece).  The
+// swizzle only depends on the low 4 bits of the row, which repeat every 4 pieces of a wave.
+__device__ __forceinline__ void slab_fast_setup(SlabOp& s, const Wave& w) {
+  s.fast = s.vec16 && s.lcpr >= 0 && s.K == s.Kp && s.mode != NPF_W_PT_COLS;
+  s.n_pw = s.Kp >> 5;  // (32 rows * Kp * 4 B / 1 KiB) / 4 waves
+  if (!s.fast) return;
+  const int rpp = 64 >> s.lcpr;             // rows per piece (1, 2, 4, 8)
+  const int lr = w.lane >> s.lcpr;           // row of this lane inside the piece
+  const int cpos = w.lane & (s.cpr - 1);     // chunk position inside the row
+  const int rstride = (s.mode == NPF_W_ROWMAJOR) ? s.ldw : 4;  // floats per matrix row step
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = (w.wave + 4 * v) * rpp + lr;  // row inside the slab (its low 4 bits are what matters)
+    const int ch = cpos ^ (row & s.swz);
+    s.lo[v] = (s.mode == NPF_W_ROWMAJOR) ? (w.wave * rpp + lr) * rstride + ch * 4
+                                          : (w.wave * rpp + lr) * 4 + ch * 128;
+  }
+  s.step = 4 * rpp * rstride;
+  s.slab_stride = (s.mode == NPF_W_ROWMAJOR) ? kSlabRows * s.ldw : s.Kp * 32;
+}
+
 struct SlabCursor {
   int op;  // index of the LINEAR op the next slab belongs to (n_ops if none)
   int nb;  // slab index inside that op
 };
 
-__device__ __forceinline__ void cursor_seek(const npf_program_t& g, SlabCursor& c) {
-  while (c.op < g.n_ops && g.ops[c.op].op != NPF_OP_LINEAR) ++c.op;
-  c.nb = 0;
+__device__ __forceinline__ void dma16(const float* src, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const float* src, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 4, 0, 0);
 }
 
-__device__ __forceinline__ void cursor_next(const npf_program_t& g, SlabCursor& c) {
-  const int NB = (g.ops[c.op].i1 + 31) >> 5;
-  if (++c.nb >= NB) {
-    ++c.op;
-    cursor_seek(g, c);
-  }
+// LDS-DMA fill of slab nb of op s into `slot`, one piece (wave-instruction) at a time.
+// 16-byte pieces (1 KiB per wave-instruction) for row-major weights with 16-byte aligned rows
+// and for the task's keys; 4-byte pieces (256 B per wave-instruction) for odd-shaped first
+// layers and the transposed values.  Piece q of the slab is issued by wave q % 8.
+struct SlabDma {
+  float* slot;
+  int row0;     // first matrix row of the slab
+  int q;        // next piece of this wave
+  int n_instr;  // pieces in the slab
+  bool on;
+};
+
+__device__ __forceinline__ SlabDma dma_begin(const SlabOp& s, int nb, const Wave& w, float* slot, bool on) {
+  SlabDma d;
+  d.slot = slot;
+  d.row0 = nb * kSlabRows;
+  d.q = w.wave;
+  d.n_instr = on ? (s.vec16 ? (s.Kp >> 3) : (s.Kp >> 1)) : 0;
+  d.on = on;
+  return d;
 }
 
-// global -> registers.  stage[i] holds float4 number tid + 512*i of the slab image.
-__device__ __forceinline__ void stage_load(const npf_program_t& g, const SlabCursor& c, const Wave& w,
-                                           f32x4 (&stage)[kStage], float& bias_stage) {
-  const npf_op_t& o = g.ops[c.op];
-  const int K = o.i0, N = o.i1, mode = o.i2;
-  const int Kp = ((K + 31) >> 5) * 32;
-  const int total = 8 * Kp;  // float4 in the slab
-  const float* W = (const float*)o.p0;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  if (mode == NPF_W_ROWMAJOR) {
-    const int ldw = o.i3;
-    W += (size_t)w.task * o.s0;
-    const bool vec_ok = ((ldw & 3) == 0) && ((o.s0 & 3) == 0) && ((((uintptr_t)o.p0) & 15) == 0);
-    const int kq = Kp >> 2;  // float4 per slab row
-#pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const int idx = w.tid + i * kThreads;
-      f32x4 v = zero4;
-      if (idx < total) {
-        const int row = idx / kq, c4 = idx - row * kq;
-        const int n = c.nb * 32 + row, k = c4 * 4;
-        if (n < N) {
-          const float* src = W + (size_t)n * ldw + k;
-          if (vec_ok && k + 4 <= K) {
-            v = *(const f32x4*)src;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (k + j < K) v[j] = src[j];
-          }
-        }
-      }
-      stage[i] = v;
+__device__ __forceinline__ void dma_piece(const SlabOp& s, SlabDma& d, const Wave& w) {
+  const float* Z = g_zero16;
+  const int lin = d.q * 64 + w.lane;
+  if (s.vec16) {
+    int row, cpos;
+    if (s.lcpr >= 0) {
+      row = lin >> s.lcpr;
+      cpos = lin & (s.cpr - 1);
+    } else {
+      row = lin / s.cpr;
+      cpos = lin - row * s.cpr;
     }
-  } else if (mode == NPF_W_PT_ROWS) {
-    // rows = points of the task's PT32 tensor (its tile nb), columns = its features
-    const float* src = W + ((size_t)w.task * o.i3 + c.nb) * (size_t)(Kp * 32);
-#pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const int idx = w.tid + i * kThreads;  // = d4 * 32 + point
-      stage[i] = (idx < total && c.nb * 32 + (idx & 31) < N) ? *(const f32x4*)(src + (size_t)idx * 4) : zero4;
-    }
+    const int ch = cpos ^ (row & s.swz);  // the matrix chunk that lives at this LDS position
+    const int n = d.row0 + row;
+    const float* src;
+    if (s.mode == NPF_W_PT_ROWS)
+      src = (n < s.N) ? s.W + (size_t)(n >> 5) * (s.Kp * 32) + ((size_t)ch * 32 + (n & 31)) * 4 : Z;
+    else
+      src = (n < s.N && ch * 4 < s.K) ? s.W + (size_t)n * s.ldw + ch * 4 : Z;
+    dma16(src, d.slot + d.q * 256);
   } else {
-    // NPF_W_PT_COLS: rows = features of the task's PT32 tensor (block nb), columns = its points
-    const int Fq = ((N + 31) >> 5) * 8;  // float4 rows per tile of the source tensor
-#pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const int idx = w.tid + i * kThreads;
-      const int n4 = idx / Kp, cpt = idx - n4 * Kp;
-      const float* src = W + (((size_t)w.task * o.i3 + (cpt >> 5)) * Fq + (c.nb * 8 + n4)) * 128 + (cpt & 31) * 4;
-      stage[i] = (idx < total && cpt < K) ? *(const f32x4*)src : zero4;
-    }
+    const int row = lin / s.Kp, colpos = lin - row * s.Kp;
+    const int col = (((colpos >> 2) ^ (row & s.swz)) << 2) | (colpos & 3);
+    const int n = d.row0 + row;
+    const float* src;
+    if (s.mode == NPF_W_PT_COLS)
+      src = (col < s.K) ? s.W + ((size_t)(col >> 5) * s.Fq + (n >> 2)) * 128 + (col & 31) * 4 + (n & 3) : Z;
+    else
+      src = (n < s.N && col < s.K) ? s.W + (size_t)n * s.ldw + col : Z;
+    dma4(src, d.slot + d.q * 64);
   }
-  bias_stage = 0.f;
-  if (w.tid < 32 && o.p1 != nullptr) {
-    const int n = c.nb * 32 + w.tid;
-    if (n < N) bias_stage = ((const float*)o.p1)[(size_t)w.task * o.s1 + n];
+  d.q += kWaves;
+}
+
+// the rest of the slab's pieces + the 64 biases of its rows
+__device__ __forceinline__ void dma_finish(const SlabOp& s, SlabDma& d, const Wave& w) {
+  if (d.on && s.fast && d.row0 + kSlabRows <= s.N) {
+    // full slab on the fast path: ~6 instructions per 1 KiB piece
+    const float* base = s.W + (size_t)(d.row0 / kSlabRows) * s.slab_stride;
+    float* dst = d.slot + w.wave * 256;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < s.n_pw) dma16(base + (size_t)(i * s.step) + s.lo[i & 3], dst + i * (kWaves * 256));
+    d.q = d.n_instr;
+  }
+  while (d.q < d.n_instr) dma_piece(s, d, w);
+  if (d.on && w.wave == 0) {
+    const int n = d.row0 + w.lane;
+    dma4((s.bias != nullptr && w.lane < kSlabRows && n < s.N) ? s.bias + n : g_zero16, d.slot + kSlabRows * s.Kp);
   }
 }
 
-// registers -> LDS slot
-__device__ __forceinline__ void stage_write(const npf_program_t& g, const SlabCursor& c, const Wave& w,
-                                            const f32x4 (&stage)[kStage], float bias_stage, float* slot) {
-  const npf_op_t& o = g.ops[c.op];
-  const int mode = o.i2;
-  const int Kp = ((o.i0 + 31) >> 5) * 32;
-  const int total = 8 * Kp;
-  const int stride = slab_stride(Kp);
-  if (mode == NPF_W_ROWMAJOR) {
-    const int kq = Kp >> 2;
-#pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const int idx = w.tid + i * kThreads;
-      if (idx < total) {
-        const int row = idx / kq, c4 = idx - row * kq;
-        *(f32x4*)(slot + row * stride + c4 * 4) = stage[i];
-      }
-    }
-  } else if (mode == NPF_W_PT_ROWS) {
-#pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const int idx = w.tid + i * kThreads;
-      if (idx < total) *(f32x4*)(slot + (idx & 31) * stride + (idx >> 5) * 4) = stage[i];
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const int idx = w.tid + i * kThreads;
-      if (idx < total) {
-        const int n4 = idx / Kp, cpt = idx - n4 * Kp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) slot[(n4 * 4 + j) * stride + cpt] = stage[i][j];
-      }
-    }
-  }
-  if (w.tid < 32) slot[kBiasOff + w.tid] = bias_stage;
-}
-
-// One 32-row slab = two 16-row output blocks (two independent accumulator chains):
-//   acc_j[n][p] = bias[n] + sum_k W[16j + n][k] cur[k][p].
+// One 32-row slab = two 16-row output blocks (independent accumulator chains):
+//   acc[j][n][p] = bias[16j + n] + sum_k W[16j + n][k] cur[k][p],  j < NBLK.
 // MFMA step s of input block kb contracts features kb*16 + 4g + s (g = lane >> 4): exactly
 // what accumulator register s of block kb holds on this lane, and what the A lane (n, g)
-// reads as element s of the float4 at W[n][kb*16 + 4g].
+// reads as element s of chunk 4*kb + g of row n.
+// KB16S > 0: the number of 16-feature input blocks is a compile-time constant (straight-line
+// code: hipcc hoists the LDS reads of later blocks above the MFMAs of earlier ones, which
+// hides the LDS latency inside one wave); KB16S == 0: runtime count with a guard per block.
+template <int NBLK, int KB16S>
 __device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wave& w, const f32x4 (&cur)[kMaxB16],
-                                          f32x4& acc0, f32x4& acc1) {
-  const int stride = slab_stride(KB16 * 16);
-  const float* a0 = slot + w.p * stride + 4 * w.g;
-  const float* a1 = a0 + 16 * stride;
-  acc0 = *(const f32x4*)(slot + kBiasOff + 4 * w.g);
-  acc1 = *(const f32x4*)(slot + kBiasOff + 16 + 4 * w.g);
+                                          f32x4 (&acc)[kBlk]) {
+  if (KB16S > 0) KB16 = KB16S;
+  const int Kp = KB16 * 16;
+  const int cpr = Kp >> 2;
+  const int swz = (cpr & 15) ? 7 : 15;
+  const int ps = w.p & swz;  // rows 16j + p: the low 4 bits are p for every block
+  const float* a = slot + w.p * Kp;
+  const float* bias = slot + kSlabRows * Kp + 4 * w.g;
 #pragma unroll
-  for (int kb = 0; kb < kMaxB16; ++kb) {
-    if (kb < KB16) {
-      const f32x4 x0 = *(const f32x4*)(a0 + kb * 16);
-      const f32x4 x1 = *(const f32x4*)(a1 + kb * 16);
+  for (int j = 0; j < NBLK; ++j) acc[j] = *(const f32x4*)(bias + 16 * j);
+  if constexpr (KB16S > 0) {
+    // Software pipeline, pinned by hand: the A fragments of block kb+1 are read (inline-asm
+    // ds_read_b128, invisible to hipcc's scheduler and waitcnt pass) BEFORE the MFMAs of block
+    // kb issue, into the other of two register sets; one s_waitcnt lgkmcnt(0) per block.
+    // hipcc itself sinks every fragment read behind the previous MFMAs to shorten live ranges
+    // and then waits for it immediately, which exposes the LDS latency in every block.
+    // Chunk (4 kb + g) ^ ps of row p: with kb = 4 m + t the lane part only depends on t.
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)a;
+    unsigned addr[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[s], cur[kb][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], cur[kb][s], acc1, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) addr[t] = lds0 + (((t ^ (ps >> 2)) << 6) | ((w.g ^ (ps & 3)) << 4));
+    constexpr int kRowBlk = 16 * KB16S * 16 * 4;  // bytes between output blocks j (16 rows)
+    f32x4 fr[2][NBLK];
+    // one statement = wait for the current fragments + issue the next ones: the "+v" operands
+    // make the MFMAs of the block depend on it, so nothing can be scheduled around the wait
+#define NPF_STEP(curf, nxtf, kbn)                                                                          \
+  if constexpr (NBLK == 2)                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6" \
+                 : "=&v"(nxtf[0]), "=&v"(nxtf[1]), "+v"(curf[0]), "+v"(curf[1])                            \
+                 : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256), "n"(((kbn) >> 2) * 256 + kRowBlk));        \
+  else                                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2 offset:%3"                                   \
+                 : "=&v"(nxtf[0]), "+v"(curf[0])                                                           \
+                 : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256));
+#define NPF_LAST(curf)                                                                    \
+  if constexpr (NBLK == 2)                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(curf[0]), "+v"(curf[1]));                  \
+  else                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(curf[0]));
+    // prologue: fragments of block 0
+    if constexpr (NBLK == 2)
+      asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:%3"
+                   : "=&v"(fr[0][0]), "=&v"(fr[0][1])
+                   : "v"(addr[0]), "n"(kRowBlk));
+    else
+      asm volatile("ds_read_b128 %0, %1 offset:0" : "=&v"(fr[0][0]) : "v"(addr[0]));
+#pragma unroll
+    for (int kb = 0; kb < KB16S; ++kb) {
+      if (kb + 1 < KB16S) {
+        if ((kb & 1) == 0) { NPF_STEP(fr[0], fr[1], kb + 1) } else { NPF_STEP(fr[1], fr[0], kb + 1) }
+      } else {
+        if ((kb & 1) == 0) { NPF_LAST(fr[0]) } else { NPF_LAST(fr[1]) }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][j][s], cur[kb][s], acc[j], 0, 0, 0);
+    }
+#undef NPF_STEP
+#undef NPF_LAST
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < kMaxB16; ++kb) {
+      if (kb < KB16) {
+        const int off = (((4 * kb + w.g) ^ ps) << 2);
+        f32x4 x[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) x[j] = *(const f32x4*)(a + j * 16 * Kp + off);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][s], cur[kb][s], acc[j], 0, 0, 0);
       }
     }
+  }
+}
+
+template <int NBLK>
+__device__ __forceinline__ void slab_mfma_any(const float* slot, int KB16, const Wave& w,
+                                              const f32x4 (&cur)[kMaxB16], f32x4 (&acc)[kBlk]) {
+  switch (KB16) {
+    case 16: slab_mfma<NBLK, 16>(slot, KB16, w, cur, acc); break;
+    case 8: slab_mfma<NBLK, 8>(slot, KB16, w, cur, acc); break;
+    case 4: slab_mfma<NBLK, 4>(slot, KB16, w, cur, acc); break;
+    case 2: slab_mfma<NBLK, 2>(slot, KB16, w, cur, acc); break;
+    default: slab_mfma<NBLK, 0>(slot, KB16, w, cur, acc); break;
   }
 }
 
@@ -209,37 +337,17 @@ __device__ __forceinline__ float xg_max(float v) {
   return fmaxf(v, __shfl_xor(v, 32));
 }
 
-#define NPF_SET_BLOCK(arr, idx, val) \
-  switch (idx) {                     \
-    case 0: arr[0] = val; break;     \
-    case 1: arr[1] = val; break;     \
-    case 2: arr[2] = val; break;     \
-    case 3: arr[3] = val; break;     \
-    case 4: arr[4] = val; break;     \
-    case 5: arr[5] = val; break;     \
-    case 6: arr[6] = val; break;     \
-    case 7: arr[7] = val; break;     \
-    case 8: arr[8] = val; break;     \
-    case 9: arr[9] = val; break;     \
-    case 10: arr[10] = val; break;   \
-    case 11: arr[11] = val; break;   \
-    case 12: arr[12] = val; break;   \
-    case 13: arr[13] = val; break;   \
-    case 14: arr[14] = val; break;   \
-    default: arr[15] = val; break;   \
-  }
-
 __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t g) {
   __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats];
 
   Wave w;
   w.tid = threadIdx.x;
-  const int lane = w.tid & 63;
-  w.p = lane & 15;
-  w.g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(w.tid >> 6);
-  w.half = wave & 1;
-  const int wtile = wave >> 1;
+  w.lane = w.tid & 63;
+  w.p = w.lane & 15;
+  w.g = w.lane >> 4;
+  w.wave = __builtin_amdgcn_readfirstlane(w.tid >> 6);
+  w.half = w.wave & 1;
+  const int wtile = w.wave >> 1;
   if (g.wg_per_task) {
     const int wgs = (g.tiles_per_task + kTilesPerWG - 1) / kTilesPerWG;
     w.task = blockIdx.x / wgs;
@@ -254,6 +362,17 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
   if (!w.valid) w.tile_in_task = 0;  // keep addresses in range; loads are zeroed, stores skipped
   const int pt = w.tile_in_task * 32 + 16 * w.half + w.p;  // point index inside the task
   const bool pt_ok = w.valid && pt < g.pts_per_task;        // real (non padding) point
+  // slab weights are per workgroup: with per-task weights every wave of the WG shares w.task
+  const int wg_task = g.wg_per_task ? w.task : 0;
+
+  // Two workgroups share each SIMD and execute the same instruction stream: started together
+  // they would stay in lockstep (equal MFMA arbitration keeps them aligned) and idle the
+  // matrix pipe during every per-slab scalar phase.  Delay the one in the odd wave slot by
+  // about half a slab period so that one workgroup's scalar phase meets the other's MFMAs.
+  if (!(g.reserved[0] & 16)) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg(6148);  // HW_REG_HW_ID[3:0] = WAVE_ID
+    if (wave_slot & 1) __builtin_amdgcn_s_sleep(40);
+  }
 
   f32x4 cur[kMaxB16], out[kMaxB16];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -264,58 +383,97 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
   }
   float acc_dot = 0.f;
 
-  f32x4 stage[kStage];
-  float bias_stage = 0.f;
+  // slab prefetch cursor: (op, slab) of the next slab to load, and that op's constants
   SlabCursor pf;
   pf.op = 0;
-  cursor_seek(g, pf);
+  pf.nb = 0;
+  SlabOp pfs;
+  pfs.n_slabs = 0;
+  pfs.fast = false;
+  auto seek = [&]() {
+    while (pf.op < g.n_ops && g.ops[pf.op].op != NPF_OP_LINEAR) ++pf.op;
+    pf.nb = 0;
+    if (pf.op < g.n_ops) {
+      pfs = make_slab_op(g.ops[pf.op], wg_task);
+      slab_fast_setup(pfs, w);
+    }
+  };
+  auto advance = [&]() {
+    if (++pf.nb >= pfs.n_slabs) {
+      ++pf.op;
+      seek();
+    }
+  };
+  seek();
   int slot = 0;
   if (pf.op < g.n_ops) {  // prologue: slab 0 of the first LINEAR
-    stage_load(g, pf, w, stage, bias_stage);
-    stage_write(g, pf, w, stage, bias_stage, smem);
-    cursor_next(g, pf);
+    SlabDma d0 = dma_begin(pfs, pf.nb, w, smem, true);
+    dma_finish(pfs, d0, w);
+    advance();
   }
-  __syncthreads();
+  __syncthreads();  // (its vmcnt(0) retires the DMA)
 
+  const float* Z = g_zero16;
   for (int ip = 0; ip < g.n_ops; ++ip) {
     const npf_op_t& o = g.ops[ip];
     const int opc = o.op;
     if (opc == NPF_OP_LINEAR) {
-      const int KB16 = ((o.i0 + 31) >> 5) * 2, NB = (o.i1 + 31) >> 5;
+      const int KB16 = ((o.i0 + 31) >> 5) * 2, N = o.i1;
+      const int NB = (N + kSlabRows - 1) / kSlabRows;
       const bool relu = (o.flags & NPF_F_RELU) != 0;
-      const bool add = (o.flags & NPF_F_ADD_PT) != 0;
-      const float* addt = add ? pt_lane(o.p2, g, w, NB * 32, o.i4) : nullptr;
+      const bool add = ((o.flags & NPF_F_ADD_PT) != 0) & w.valid;
+      const float* addt = add ? pt_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4) : Z;
+      const int astep = add ? 128 : 0;  // (no addend: every load reads the zero buffer)
+      // Runtime slab loop with *static* register indices: finished blocks enter a register
+      // queue (out[] shifts down by one slab per iteration), so the loop body exists once
+      // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
+      // cache) and no dynamically indexed register array is needed.
       for (int nb = 0; nb < NB; ++nb) {
-        const bool has_next = pf.op < g.n_ops;
-        if (has_next) stage_load(g, pf, w, stage, bias_stage);
-        f32x4 ad0 = zero4, ad1 = zero4;
-        if (add && w.valid) {
-          ad0 = *(const f32x4*)(addt + (8 * nb + w.g) * 128);
-          ad1 = *(const f32x4*)(addt + (8 * nb + 4 + w.g) * 128);
+        // 1. start filling the other slot with the next slab (possibly the next layer's)
+        if (pf.op < g.n_ops) {
+          SlabDma d = dma_begin(pfs, pf.nb, w, smem + (slot ^ 1) * kSlabFloats, !(g.reserved[0] & 1));
+          dma_finish(pfs, d, w);
+          advance();
         }
-        f32x4 acc0, acc1;
-        slab_mfma(smem + slot * kSlabFloats, KB16, w, cur, acc0, acc1);
-        if (has_next) {
-          stage_write(g, pf, w, stage, bias_stage, smem + (slot ^ 1) * kSlabFloats);
-          cursor_next(g, pf);
+        // 2. addend tiles (consumed after the barrier)
+        f32x4 ad[kBlk];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) ad[j] = *(const f32x4*)(addt + (4 * kBlk * nb + 4 * j + w.g) * astep);
+        // 3. the slab's MFMAs
+        f32x4 acc[kBlk];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) acc[j] = zero4;
+        const float* sl = smem + slot * kSlabFloats;
+        if (!(g.reserved[0] & 8)) {
+          if (N - nb * kSlabRows > 16) slab_mfma_any<2>(sl, KB16, w, cur, acc);
+          else slab_mfma_any<1>(sl, KB16, w, cur, acc);
         }
-        __syncthreads();
+        if (!(g.reserved[0] & 4)) __syncthreads();  // slab consumed by all waves; vmcnt(0) lands the next one
         slot ^= 1;
-        acc0 += ad0;
-        acc1 += ad1;
-        if (relu) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            acc0[s] = fmaxf(acc0[s], 0.f);
-            acc1[s] = fmaxf(acc1[s], 0.f);
+        for (int b = 0; b < kMaxB16 - kBlk; ++b) out[b] = out[b + kBlk];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+          f32x4 v = acc[j] + ad[j];
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
+          out[kMaxB16 - kBlk + j] = v;
         }
-        NPF_SET_BLOCK(out, 2 * nb, acc0);
-        NPF_SET_BLOCK(out, 2 * nb + 1, acc1);
       }
+      // the layer's blocks now sit at out[16 - 2 NB .. 15]
+#define NPF_TAKE(nbv)                                     \
+  case nbv:                                               \
+    _Pragma("unroll") for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv]; \
+    break;
+      switch (NB) {
+        NPF_TAKE(1) NPF_TAKE(2) NPF_TAKE(3) NPF_TAKE(4) NPF_TAKE(5) NPF_TAKE(6) NPF_TAKE(7)
+        default:
 #pragma unroll
-      for (int b = 0; b < kMaxB16; ++b)
-        if (b < 2 * NB) cur[b] = out[b];
+          for (int b = 0; b < kMaxB16; ++b) cur[b] = out[b];
+      }
+#undef NPF_TAKE
     } else if (opc == NPF_OP_LOAD_PT || opc == NPF_OP_ADD_PT || opc == NPF_OP_MASK_POS || opc == NPF_OP_ROWDOT_PT ||
                opc == NPF_OP_SOFTMAX_BWD) {
       const int FB = o.i0 >> 4;

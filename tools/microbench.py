@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the chain / wgrad kernels (development aid; not part of the product
+contract).  Each case builds a program directly and times it with HIP events."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from npf_gwwaveform_amd import chain as CH  # noqa: E402
+
+DEV = "cuda:0"
+PEAK = 157.3
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+def report(name, flops, sec):
+    tf = flops / sec * 1e-12
+    print(f"{name:55s} {sec*1e3:8.3f} ms  {tf:7.1f} TF/s  {100*tf/PEAK:5.1f}% of fp32 peak", flush=True)
+
+
+def chain_case(name, n_tasks, pts, layers, store=False, relu=True, per_task=False):
+    """layers: list of (K, N)."""
+    K0 = layers[0][0]
+    x = torch.randn(CH.pt_shape(n_tasks, pts, K0), device=DEV)
+    Ws = [torch.randn(N, K, device=DEV) / math.sqrt(K) for K, N in layers]
+    bs = [torch.randn(N, device=DEV) * 0.1 for K, N in layers]
+    bufs = [CH.pt_empty(n_tasks, pts, N, DEV) for K, N in layers]
+    prog = CH.Program(n_tasks, pts, per_task)
+    prog.load_pt(x, K0)
+    for (K, N), W, b, buf in zip(layers, Ws, bs, bufs):
+        prog.linear(W, K, N, bias=b, relu=relu)
+        if store:
+            prog.store_pt(buf, N)
+    if not store:
+        prog.store_pt(bufs[-1], layers[-1][1])
+    report(name, prog.flops(), timeit(prog._launch))
+
+
+def attn_case(name, B, C, T, r):
+    q = torch.randn(CH.pt_shape(B, T, r), device=DEV)
+    k = torch.randn(CH.pt_shape(B, C, r), device=DEV)
+    v = torch.randn(CH.pt_shape(B, C, r), device=DEV)
+    o = CH.pt_empty(B, T, r, DEV)
+    prog = CH.Program(B, T, True)
+    prog.load_pt(q, r)
+    prog.linear(k, r, C, mode=CH.L.W_PT_ROWS, w_tiles=k.shape[1])
+    prog.softmax(C, 1 / math.sqrt(r))
+    prog.linear(v, C, r, mode=CH.L.W_PT_COLS, w_tiles=v.shape[1])
+    prog.store_pt(o, r)
+    report(name, prog.flops(), timeit(prog._launch))
+
+
+def wgrad_case(name, n_tasks, pts, shapes, per_task=False):
+    jobs = []
+    for N, K in shapes:
+        dz = torch.randn(CH.pt_shape(n_tasks, pts, N), device=DEV)
+        a = torch.randn(CH.pt_shape(n_tasks, pts, K), device=DEV)
+        if per_task:
+            dW = torch.empty(CH.pt_shape(n_tasks, N, K), device=DEV)
+            jobs.append(dict(dZ=dz, A=a, N=N, K=K, dW=dW, per_task=True))
+        else:
+            jobs.append(dict(dZ=dz, A=a, N=N, K=K, dW=torch.empty(N, K, device=DEV), db=torch.empty(N, device=DEV)))
+    fl = sum(2 * N * K for N, K in shapes) * n_tasks * pts
+    report(name, fl, timeit(lambda: CH._run_wgrad(jobs, n_tasks, pts, DEV)))
+
+
+if __name__ == "__main__":
+    B, T, C = 256, 1024, 256
+    which = sys.argv[1:] or ["chain", "attn", "wgrad"]
+    if "chain" in which:
+        chain_case("8 x linear 256->256, relu, store last", B, T, [(256, 256)] * 8)
+        chain_case("8 x linear 256->256, relu, store every layer", B, T, [(256, 256)] * 8, store=True)
+        chain_case("1 x linear 256->256", B, T, [(256, 256)])
+        chain_case("8 x linear 128->128", B, T, [(128, 128)] * 8)
+        chain_case("8 x linear 64->64", B, T, [(64, 64)] * 8)
+        chain_case("32->256 then 7 x 256->256", B, T, [(32, 256)] + [(256, 256)] * 7)
+        chain_case("8 x [256->32]", B, T, [(256, 32), (32, 256)] * 4)
+        chain_case("8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+    if "ablate" in which:
+        for bits, name in [(0, "full"), (1, "no slab DMA"), (2, "no bias loads"), (4, "no barrier"), (8, "no MFMA"),
+                           (9, "no MFMA, no DMA"), (15, "nothing"), (16, "no start skew")]:
+            CH.DEBUG_ABLATE = bits
+            chain_case(f"ablate[{name}] 8 x linear 256->256", B, T, [(256, 256)] * 8)
+        CH.DEBUG_ABLATE = 0
+    if "attn" in which:
+        attn_case("attention fwd B256 C256 T1024 r256", B, C, T, 256)
+        attn_case("attention fwd B256 C64 T1024 r64", B, 64, T, 64)
+    if "wgrad" in which:
+        wgrad_case("wgrad 1 job 256x256 (target pts)", B, T, [(256, 256)])
+        wgrad_case("wgrad 7 jobs 256x256 (target pts)", B, T, [(256, 256)] * 7)
+        wgrad_case("wgrad 7 jobs 256x256 (ctx pts)", B, C, [(256, 256)] * 7)
+        wgrad_case("wgrad per-task 2 jobs 256x256 (attention dK,dV)", B, T, [(256, 256)] * 2, per_task=True)
+        wgrad_case("wgrad 4x256 + 256x32 + 32x2", B, T, [(4, 256), (256, 32), (32, 2)])
