@@ -64,7 +64,10 @@ enum npf_opcode {
   NPF_OP_ROWDOT_PT = 10,   /* acc0 <- sum_f cur[f] * PT32 p0[f] (i0 = F)   [softmax bwd delta]  */
   NPF_OP_SOFTMAX_BWD = 11, /* cur <- f0 * P * (cur - acc0), P = PT32 p0 (i0 = F)                */
   NPF_OP_RELU = 12,        /* cur <- max(cur, 0)                                                */
-  NPF_OP_SCALE = 13        /* cur <- f0 * cur                                                   */
+  NPF_OP_SCALE = 13,       /* cur <- f0 * cur                                                   */
+  NPF_OP_STORE_TR = 14     /* row-major p0 [task][i0 features][i1 >= 32*tiles points] <- cur: a
+                              feature-major copy, i.e. the activations as NPF_W_ROWMAJOR per-task
+                              weights W[n = feature][k = point] (s0 = i0*i1, i3 = i1)            */
 };
 
 enum npf_wmode {
@@ -77,6 +80,7 @@ enum npf_wmode {
 
 #define NPF_F_RELU 1u
 #define NPF_F_ADD_PT 2u /* add PT32 tensor p2 (same F as the output) before the activation     */
+#define NPF_F_MASK_PT 4u /* out = (PT32 tensor p2 > 0) ? out : 0 (fused relu backward); not with ADD_PT */
 
 typedef struct npf_op {
   int32_t op;        /* npf_opcode                                                              */

@@ -188,10 +188,12 @@ class DotAttender(nn.Module):
         self.is_normalize, self.is_resize = True, False
         self.dropout = nn.Identity()
 
-    def append_to(self, ch: Chain, keys_pt, values_pt, n_keys: int) -> Chain:
-        """cur = queries on entry, context vectors on exit."""
+    def append_to(self, ch: Chain, keys_pt, values_pt, n_keys: int, keys_tr=None, values_tr=None) -> Chain:
+        """cur = queries on entry, context vectors on exit.  ``keys_tr`` / ``values_tr``:
+        feature-major copies of the keys / values (``Chain.store_tr``) for the DMA fast path."""
         scale = 1.0 / math.sqrt(self.kq_size) if self.is_scale else 1.0
-        return ch.attn_scores(keys_pt, n_keys).softmax(scale).attn_values(values_pt, self.value_size)
+        return (ch.attn_scores(keys_pt, n_keys, keys_tr=keys_tr).softmax(scale)
+                .attn_values(values_pt, self.value_size, values_tr=values_tr))
 
     def forward(self, keys, queries, values):
         B, C, d = keys.shape

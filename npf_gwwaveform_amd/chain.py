@@ -78,6 +78,15 @@ class Program:
         self._op(op=L.OP_ADD_PT, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
 
     def mask_pos(self, t, F):
+        last = self.ops[-1] if self.ops else None
+        if (last is not None and last.op == L.OP_LINEAR and not (last.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_RELU))
+                and pad32(last.i1) == pad32(F)):
+            # fuse the relu-backward mask into the producing layer's epilogue: the mask tile is
+            # then prefetched under that layer's MFMAs instead of being waited for afterwards
+            last.flags |= L.F_MASK_PT
+            last.p2 = self._p(t)
+            last.i4 = 0
+            return
         self._op(op=L.OP_MASK_POS, i0=pad32(F), p0=self._p(t))
 
     def rowdot_pt(self, t, F):
@@ -85,6 +94,9 @@ class Program:
 
     def softmax_bwd(self, t, F, scale):
         self._op(op=L.OP_SOFTMAX_BWD, i0=pad32(F), f0=scale, p0=self._p(t))
+
+    def store_tr(self, t, F, ld):
+        self._op(op=L.OP_STORE_TR, i0=F, i1=ld, p0=self._p(t))
 
     def load_rows(self, t, kd, modulus=0):
         self._op(op=L.OP_LOAD_ROWS, i0=kd, i4=modulus, p0=self._p(t))
@@ -246,13 +258,15 @@ class Chain:
         self.steps.append(_Step("add_taskvec", {"v": self._t(v)}, {"F": self.F, "relu": relu, "mod": modulus}))
         return self
 
-    def attn_scores(self, keys_pt: torch.Tensor, n_keys: int) -> "Chain":
-        """cur[c] <- sum_d keys[c][d] cur[d] (DotAttender.score, attention.py:204-220, unscaled)."""
+    def attn_scores(self, keys_pt: torch.Tensor, n_keys: int, keys_tr: Optional[torch.Tensor] = None) -> "Chain":
+        """cur[c] <- sum_d keys[c][d] cur[d] (DotAttender.score, attention.py:204-220, unscaled).
+        ``keys_tr``: optional feature-major copy [n_tasks, d, 32*tiles] of the keys (``store_tr``):
+        lets the backward pass stream K^T by LDS-DMA."""
         if not self.wg_per_task:
             raise ValueError("attention needs wg_per_task=True")
         if n_keys > L.NPF_MAX_FEATURES:
             raise NotImplementedError(f"more than {L.NPF_MAX_FEATURES} context points per task are not supported yet")
-        self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F}))
+        self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F, "tr": keys_tr}))
         self.F = n_keys
         return self
 
@@ -260,15 +274,21 @@ class Chain:
         self.steps.append(_Step("softmax", {}, {"n": self.F, "scale": float(scale)}))
         return self
 
-    def attn_values(self, values_pt: torch.Tensor, r: int) -> "Chain":
-        """cur[n] <- sum_c values[c][n] cur[c] (torch.bmm(attn, values), attention.py:151)."""
-        self.steps.append(_Step("attn_values", {"v": self._t(values_pt)}, {"C": self.F, "r": r}))
+    def attn_values(self, values_pt: torch.Tensor, r: int, values_tr: Optional[torch.Tensor] = None) -> "Chain":
+        """cur[n] <- sum_c values[c][n] cur[c] (torch.bmm(attn, values), attention.py:151).
+        ``values_tr``: optional feature-major copy [n_tasks, r, 32*tiles] of the values."""
+        self.steps.append(_Step("attn_values", {"v": self._t(values_pt)}, {"C": self.F, "r": r, "tr": values_tr}))
         self.F = r
         return self
 
     # ---- outputs
     def tap(self) -> "Chain":
         self.steps.append(_Step("tap", {}, {"F": self.F}))
+        return self
+
+    def store_tr(self) -> "Chain":
+        """Extra (non-differentiable) output: feature-major copy [n_tasks, F, 32*tiles] of cur."""
+        self.steps.append(_Step("store_tr", {}, {"F": self.F}))
         return self
 
     def output_pt(self) -> "Chain":
@@ -302,6 +322,7 @@ class _ChainFn(torch.autograd.Function):
 
         saved = {}      # (step index, role) -> PT tensor
         outputs = []
+        non_diff = []
         backed = None   # PT tensor currently holding cur (None if cur only lives in registers)
         upstream = False  # does cur depend on something that needs a gradient
         upstream_before = []
@@ -363,9 +384,18 @@ class _ChainFn(torch.autograd.Function):
                 vv = st.t["v"]
                 if train and needs_grad[vv]:
                     saved[(i, "in")] = ensure_saved(a["C"])
-                prog.linear(T[vv], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=ctx_tiles(vv))
+                if a["tr"] is not None:
+                    ld = a["tr"].shape[2]
+                    prog.linear(a["tr"], a["C"], a["r"], mode=L.W_ROWMAJOR, ldw=ld, w_task_stride=a["r"] * ld)
+                else:
+                    prog.linear(T[vv], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=ctx_tiles(vv))
                 backed = None
                 upstream = upstream or needs_grad[vv]
+            elif k == "store_tr":
+                o = torch.empty((chain.n_tasks, a["F"], 32 * tiles_of(chain.pts)), dtype=torch.float32, device=dev)
+                prog.store_tr(o, a["F"], o.shape[2])
+                outputs.append(o)
+                non_diff.append(o)
             elif k in ("tap", "output_pt"):
                 # an output must own its storage: never alias an input tensor
                 if backed is not None and any(backed is t for t in T):
@@ -380,6 +410,8 @@ class _ChainFn(torch.autograd.Function):
         prog.launch()
         ctx.chain, ctx.saved, ctx.T, ctx.needs_grad, ctx.upstream_before = chain, saved, T, needs_grad, upstream_before
         ctx.train = train
+        if non_diff:
+            ctx.mark_non_differentiable(*non_diff)
         return tuple(outputs)
 
     @staticmethod
@@ -405,11 +437,14 @@ class _ChainFn(torch.autograd.Function):
                 return buf.view(chain.n_tasks // mod, mod, *buf.shape[1:]).sum(0)
             return buf
 
-        n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows"))
+        n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows", "store_tr"))
         assert len(gouts) == n_out
         for i in range(len(chain.steps) - 1, -1, -1):
             st = chain.steps[i]
             k, a = st.kind, st.a
+            if k == "store_tr":
+                gouts.pop()
+                continue
             if k in ("output_pt", "output_rows", "tap"):
                 g = gouts.pop()
                 if g is None:
@@ -484,7 +519,11 @@ class _ChainFn(torch.autograd.Function):
                     jobs.append(dict(dZ=dS, A=saved[(i, "in")], N=a["C"], K=a["r"], dW=dK, per_task=True))
                     grads[kk] = dK
                 if upstream_before[i]:
-                    prog.linear(T[kk], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=T[kk].shape[1])
+                    if a["tr"] is not None:
+                        ld = a["tr"].shape[2]
+                        prog.linear(a["tr"], a["C"], a["r"], mode=L.W_ROWMAJOR, ldw=ld, w_task_stride=a["r"] * ld)
+                    else:
+                        prog.linear(T[kk], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=T[kk].shape[1])
                 else:
                     break
             elif k == "input_pt":

@@ -421,7 +421,8 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
       const int KB16 = ((o.i0 + 31) >> 5) * 2, N = o.i1;
       const int NB = (N + kSlabRows - 1) / kSlabRows;
       const bool relu = (o.flags & NPF_F_RELU) != 0;
-      const bool add = ((o.flags & NPF_F_ADD_PT) != 0) & w.valid;
+      const bool mask = (o.flags & NPF_F_MASK_PT) != 0;  // out = (tile > 0) ? acc : 0  (relu backward)
+      const bool add = ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid;
       const float* addt = add ? pt_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4) : Z;
       const int astep = add ? 128 : 0;  // (no addend: every load reads the zero buffer)
       // Runtime slab loop with *static* register indices: finished blocks enter a register
@@ -454,7 +455,13 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
         for (int b = 0; b < kMaxB16 - kBlk; ++b) out[b] = out[b + kBlk];
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) {
-          f32x4 v = acc[j] + ad[j];
+          f32x4 v;
+          if (mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ad[j][e] > 0.f ? acc[j][e] : 0.f;
+          } else {
+            v = acc[j] + ad[j];
+          }
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -504,6 +511,20 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
 #pragma unroll
         for (int b = 0; b < kMaxB16; ++b)
           if (b < FB) *(f32x4*)(t + (4 * b + w.g) * 128) = cur[b];
+      }
+    } else if (opc == NPF_OP_STORE_TR) {
+      // feature-major copy [task][feature][point]: the layout the slab DMA wants when these
+      // activations are used as per-task weights with the points as the contraction index
+      const int F = o.i0, ld = o.i1;
+      float* dst = (float*)o.p0 + (size_t)w.task * F * ld + pt;
+      if (w.valid) {
+#pragma unroll
+        for (int b = 0; b < kMaxB16; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int f = 16 * b + 4 * w.g + e;
+            if (f < F) dst[(size_t)f * ld] = cur[b][e];
+          }
       }
     } else if (opc == NPF_OP_LOAD_ROWS) {
       const int kd = o.i0;
@@ -594,7 +615,8 @@ static int validate(const npf_program_t* g) {
         if (o.i2 == NPF_W_PT_ROWS && o.i3 * 32 < o.i1) return NPF_EINVAL;
         if (o.i2 == NPF_W_PT_COLS && o.i3 * 32 < o.i0) return NPF_EINVAL;
         if (o.i2 != NPF_W_ROWMAJOR && (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
-        if ((o.flags & NPF_F_ADD_PT) && (!o.p2 || (((uintptr_t)o.p2) & 15))) return NPF_EINVAL;
+        if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) && (!o.p2 || (((uintptr_t)o.p2) & 15))) return NPF_EINVAL;
+        if ((o.flags & NPF_F_ADD_PT) && (o.flags & NPF_F_MASK_PT)) return NPF_EINVAL;
         if (o.s1 != 0 && !g->wg_per_task) return NPF_EINVAL;
         break;
       case NPF_OP_LOAD_PT:
@@ -614,6 +636,9 @@ static int validate(const npf_program_t* g) {
         break;
       case NPF_OP_SOFTMAX:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES) return NPF_EINVAL;
+        break;
+      case NPF_OP_STORE_TR:
+        if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || !o.p0 || o.i1 < g->tiles_per_task * 32) return NPF_EINVAL;
         break;
       case NPF_OP_RELU:
       case NPF_OP_SCALE:

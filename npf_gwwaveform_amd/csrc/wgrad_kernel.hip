@@ -8,17 +8,17 @@
 // read gives a lane 4 *features* of one point.  With v_mfma_f32_16x16x4_f32 the 4 k-slots are
 // 4 consecutive points (lane group g), the lane's row/column is a feature *quad* and the 16
 // MFMAs (m, m') of a step use element m of the dZ read and element m' of the A read: one pair
-// of ds_read_b128 feeds 16 MFMAs = a 64 x 64 block of dW.  A workgroup (8 waves, 2 per SIMD)
-// owns the whole <= 256 x 256 dW: wave w holds rows 64*(w>>1).. and columns 128*(w&1).. in
-// 128 accumulator registers, streams its tiles through one LDS buffer (register-staged
-// prefetch of the next tile) and writes one partial; a second tiny kernel sums the partials
-// of the workgroups that split the points (deterministic, no atomics).
+// of ds_read_b128 feeds 16 MFMAs = a 64 x 64 block of dW.  A workgroup (16 waves, 4 per SIMD)
+// owns the whole <= 256 x 256 dW: wave w holds the 64 x 64 block (w>>2, w&3) in 64 accumulator
+// registers, streams its tiles by LDS-DMA through a double-buffered, XOR-
+// swizzled LDS image (one barrier per tile) and writes one partial; a second tiny kernel sums
+// the partials of the workgroups that split the points (deterministic, no atomics).
 #include "npf_common.hpp"
 
 namespace npf {
 
-constexpr int kWgThreads = 512;
-constexpr int kQStride = 136;              // floats per feature-quad row in LDS: 32 pts * 4 + 8 pad
+constexpr int kWgThreads = 1024;
+constexpr int kWgWaves = kWgThreads / 64;
 constexpr int kQRows = NPF_MAX_FEATURES / 4;  // 64 quad rows per operand
 constexpr int kMaxJobs = 16;
 
@@ -32,10 +32,18 @@ struct WgradJobs {
   int64_t part_off[kMaxJobs];      // float offset of each job's partial slabs (shared-weight jobs)
 };
 
-__global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(const WgradJobs J, float* __restrict__ partials) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kQRows * kQStride];
-  float* ldz = lds;
-  float* lda = lds + kQRows * kQStride;
+__device__ __forceinline__ void wg_dma16(const float* src, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+// LDS image of one tile of one operand: [F/4 feature-quad rows][32 points] 16-byte chunks,
+// dense (512 B per row), chunk c of row r stored at chunk position c ^ (r & 15): the fragment
+// read (16 quad rows x 4 consecutive points per ds_read_b128) is then bank-conflict free and
+// a 1 KiB LDS-DMA piece (2 rows) lands linearly with the swizzle applied to its source address.
+__global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kQRows * 128];  // 2 buffers x (dZ, A)
+  constexpr int kOp = kQRows * 128;  // floats per operand image
 
   int j = 0;
   while (j + 1 < J.n_jobs && (int)blockIdx.x >= J.first_wg[j + 1]) ++j;
@@ -56,138 +64,120 @@ __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(const WgradJobs J,
   const int tid = threadIdx.x, lane = tid & 63;
   const int i = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wave >> 1, ch = wave & 1;
-  const bool act_a = 64 * rg < Np;
-  const bool act_b0 = act_a && (128 * ch < Kp);
-  const bool act_b1 = act_a && (128 * ch + 64 < Kp);
+  // 64 x 64 block (rg, cg) of dW owned by this wave.  Consecutive waves sit on different SIMDs,
+  // so the narrower block dimension goes to the slow-varying index: a skinny job (one active
+  // block row or column) then has one active wave per SIMD instead of four on one SIMD.
+  const bool wide_rows = ((Kp + 63) >> 6) < ((Np + 63) >> 6);
+  const int rg = wide_rows ? (wave & 3) : (wave >> 2);
+  const int cg = wide_rows ? (wave >> 2) : (wave & 3);
+  const bool act = (64 * rg < Np) && (64 * cg < Kp);
 
-  // zero the LDS once: quad rows beyond Np/4, Kp/4 stay zero for the whole kernel
-  for (int x = tid; x < 2 * kQRows * kQStride; x += kWgThreads) lds[x] = 0.f;
+  // zero the LDS once: quad rows beyond Np/4, Kp/4 are never written and must read as zero
+  for (int x = tid; x < 2 * 2 * kOp; x += kWgThreads) lds[x] = 0.f;
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc0[4][4], acc1[4][4];
+  f32x4 acc[4][4];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      acc0[m][n] = zero4;
-      acc1[m][n] = zero4;
-    }
+    for (int n = 0; n < 4; ++n) acc[m][n] = zero4;
   f32x4 dbacc = zero4;
 
-  const int nz4 = 8 * Np, na4 = 8 * Kp;  // float4 per tile of each operand
-  f32x4 sz[4], sa[4];
-  auto stage_load = [&](long t) {
-    const float* zsrc = job.dZ + (size_t)t * Np * 32;
-    const float* asrc = job.A + (size_t)t * Kp * 32;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * kWgThreads;
-      sz[u] = idx < nz4 ? *(const f32x4*)(zsrc + (size_t)idx * 4) : zero4;
-      sa[u] = idx < na4 ? *(const f32x4*)(asrc + (size_t)idx * 4) : zero4;
-    }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * kWgThreads;
-      if (idx < nz4) *(f32x4*)(ldz + (idx >> 5) * kQStride + (idx & 31) * 4) = sz[u];
-      if (idx < na4) *(f32x4*)(lda + (idx >> 5) * kQStride + (idx & 31) * 4) = sa[u];
-    }
+  // DMA: piece q of an operand = its quad rows 2q, 2q+1; wave w issues pieces w, w+16, ...: the
+  // swizzle term (row & 15) = (2w + (lane >> 5)) & 15 is the same for all of them
+  const int dma_lane = (lane >> 5) * 128 + (((lane & 31) ^ ((2 * wave + (lane >> 5)) & 15)) << 2);
+  auto tile_dma = [&](long t, float* buf) {
+    const float* zsrc = job.dZ + (size_t)t * Np * 32 + dma_lane;
+    const float* asrc = job.A + (size_t)t * Kp * 32 + dma_lane;
+    for (int q = wave; q < (Np >> 3); q += kWgWaves) wg_dma16(zsrc + q * 256, buf + q * 256);
+    for (int q = wave; q < (Kp >> 3); q += kWgWaves) wg_dma16(asrc + q * 256, buf + kOp + q * 256);
   };
 
   __syncthreads();
-  if (t0 < t1) {
-    stage_load(t0);
-    stage_write();
+  if (t0 < t1) tile_dma(t0, lds);
+
+  // fragment addresses: chunk (4 s + g) ^ i of quad row (base + i); with s = 4 m + t the lane
+  // part only depends on t (4 address registers per operand, m goes to the immediate offset)
+  unsigned za_l[4], ab_l[4];
+  {
+    const unsigned l0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned lanepart = (((t ^ (i >> 2)) << 2) | (g ^ (i & 3))) << 4;
+      za_l[t] = l0 + (16 * rg + i) * 512 + lanepart;
+      ab_l[t] = l0 + kOp * 4 + (16 * cg + i) * 512 + lanepart;
+    }
   }
-  __syncthreads();
 
-  const float* za = ldz + (16 * rg + i) * kQStride + 4 * g;
-  const float* ab0 = lda + (32 * ch + i) * kQStride + 4 * g;
-  const float* ab1 = ab0 + 16 * kQStride;
   for (long t = t0; t < t1; ++t) {
-    const bool more = t + 1 < t1;
-    if (more) stage_load(t + 1);
-    if (act_a) {
+    const int cur = (int)((t - t0) & 1);
+    __syncthreads();  // vmcnt(0): tile t has landed; everyone is done with the other buffer
+    if (t + 1 < t1) tile_dma(t + 1, lds + (cur ^ 1) * 2 * kOp);
+    const unsigned boff = cur * 2 * kOp * 4;
+    if (act) {
+      // 8 steps of 4 points; the fragments of step s+1 are read (inline asm, pinned) before the 16
+      // MFMAs of step s issue: hipcc otherwise reads them right before use and exposes the LDS
+      // latency 8 times per tile
+      f32x4 fa[2], fb[2];
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                   : "=&v"(fa[0]), "=&v"(fb[0])
+                   : "v"(za_l[0] + boff), "v"(ab_l[0] + boff));
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const f32x4 a4 = *(const f32x4*)(za + 16 * s);  // 4 features of point 4s+g
-        if (ch == 0) dbacc += a4;
-        if (act_b0) {
-          const f32x4 b4 = *(const f32x4*)(ab0 + 16 * s);
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-              acc0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], b4[n], acc0[m][n], 0, 0, 0);
+        const int c = s & 1, n = c ^ 1;
+        if (s + 1 < 8) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6"
+                       : "=&v"(fa[n]), "=&v"(fb[n]), "+v"(fa[c]), "+v"(fb[c])
+                       : "v"(za_l[(s + 1) & 3] + boff), "v"(ab_l[(s + 1) & 3] + boff), "n"(((s + 1) >> 2) * 256));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb[c]));
         }
-        if (act_b1) {
-          const f32x4 b4 = *(const f32x4*)(ab1 + 16 * s);
+        if (cg == 0) dbacc += fa[c];
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-              acc1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], b4[n], acc1[m][n], 0, 0, 0);
-        }
+          for (int n2 = 0; n2 < 4; ++n2)
+            acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][m], fb[c][n2], acc[m][n2], 0, 0, 0);
       }
-    }
-    __syncthreads();
-    if (more) {
-      stage_write();
-      __syncthreads();
     }
   }
 
   // ---- write out --------------------------------------------------------------------
-  // accX[m][n][e] on lane (i, g) = D[row 4*(16rg + 4g + e) + m][col 4*(32ch + 16x + i) + n]
-  if (job.per_task) {
-    // PT32 tensor, points = row index (n of dW), features = column index (k)
-    float* out = job.dW + (size_t)split * ((Np >> 5) * Kp * 32);
-    if (act_a) {
+  // acc[m][n][e] on lane (i, g) = D[row 4*(16rg + 4g + e) + m][col 4*(16cg + i) + n]
+  if (act) {
+    const int col = 4 * (16 * cg + i);
+    if (job.per_task) {
+      // PT32 tensor, points = row index (n of dW), features = column index (k)
+      float* out = job.dW + (size_t)split * ((Np >> 5) * Kp * 32);
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        if (x == 0 ? act_b0 : act_b1) {
-          const int kq = 32 * ch + 16 * x + i;  // feature quad of the output
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+        for (int e = 0; e < 4; ++e) {
+          const int row = 4 * (16 * rg + 4 * g + e) + m;
+          if (row < Np && col < Kp) {
+            f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int row = 4 * (16 * rg + 4 * g + e) + m;
-              if (row < Np && 4 * kq < Kp) {
-                f32x4 v;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) v[n] = x == 0 ? acc0[m][n][e] : acc1[m][n][e];
-                float* dst = out + ((size_t)(row >> 5) * (Kp >> 2) + kq) * 128 + (row & 31) * 4;
-                if (job.accumulate) v += *(const f32x4*)dst;
-                *(f32x4*)dst = v;
-              }
-            }
+            for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
+            float* dst = out + ((size_t)(row >> 5) * (Kp >> 2) + (col >> 2)) * 128 + (row & 31) * 4;
+            if (job.accumulate) v += *(const f32x4*)dst;
+            *(f32x4*)dst = v;
+          }
         }
-      }
-    }
-  } else {
-    float* part = partials + J.part_off[j] + (size_t)split * ((size_t)Np * Kp + Np);
-    if (act_a) {
+    } else {
+      float* part = partials + J.part_off[j] + (size_t)split * ((size_t)Np * Kp + Np);
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        if (x == 0 ? act_b0 : act_b1) {
-          const int col = 4 * (32 * ch + 16 * x + i);
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+        for (int e = 0; e < 4; ++e) {
+          const int row = 4 * (16 * rg + 4 * g + e) + m;
+          if (row < Np && col < Kp) {
+            f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int row = 4 * (16 * rg + 4 * g + e) + m;
-              if (row < Np && col < Kp) {
-                f32x4 v;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) v[n] = x == 0 ? acc0[m][n][e] : acc1[m][n][e];
-                *(f32x4*)(part + (size_t)row * Kp + col) = v;
-              }
-            }
+            for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
+            *(f32x4*)(part + (size_t)row * Kp + col) = v;
+          }
         }
-      }
-      if (ch == 0) {
+      if (cg == 0) {
         // dbacc[m] on lane (i, g): sum over the points = g (mod 4) of feature 4*(16rg+i)+m
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -238,9 +228,14 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
     if (!b.per_task && b.ldw < b.K) return NPF_EINVAL;
     n_shared += b.per_task ? 0 : 1;
   }
-  long splits = n_shared ? 256 / n_shared : 1;
-  if (splits < 1) splits = 1;
-  if (splits > total_tiles) splits = total_tiles;
+  // workgroups per shared-weight job, proportional to its per-tile time: with the wave mapping
+  // of wgrad_kernel a job with min(row blocks, column blocks) = b keeps b waves per SIMD busy
+  double cost[kMaxJobs], cost_sum = 0.0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const int ar = (npf::round_up(jobs[j].N, 32) + 63) / 64, ac = (npf::round_up(jobs[j].K, 32) + 63) / 64;
+    cost[j] = jobs[j].per_task ? 0.0 : (double)(ar < ac ? ar : ac) / 4.0;
+    cost_sum += cost[j];
+  }
   J->n_jobs = n_jobs;
   J->n_tasks = n_tasks;
   J->tiles_per_task = tiles_per_task;
@@ -255,6 +250,11 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
       wg += n_tasks;
     } else {
       const int Np = npf::round_up(jobs[j].N, 32), Kp = npf::round_up(jobs[j].K, 32);
+      // floor: the shared-weight jobs of one launch must fit one wave of 256 workgroups (one per
+      // CU), a 257th workgroup would wait for a second round
+      long splits = (long)(256.0 * cost[j] / cost_sum);
+      if (splits < 1) splits = 1;
+      if (splits > total_tiles) splits = total_tiles;
       wg += (int)splits;
       off += (int64_t)splits * ((int64_t)Np * Kp + Np);
     }

@@ -108,7 +108,7 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         T = X_trgt.shape[1]
         if T == 0:
             raise ValueError("no target points")
-        Xc_pt = self._xenc_pt(X_cntxt) if C > 0 else None
+        Xc_pt = self._xenc_pt(X_cntxt, with_tr=self._attentive) if C > 0 else None
         Xt_pt = self._xenc_pt(X_trgt)
         R = self._encode_globally_pt(Xc_pt, Y_cntxt, B, C)
         if self.encoded_path in ["latent", "both"]:
@@ -133,19 +133,31 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
                 raise ValueError(f"Features during training should be in [-1,1]. Got [{lo}, {hi}].")
 
     # ------------------------------------------------------------------ PT-level stages
-    def _xenc_pt(self, X):
+    _attentive = False  # attentive subclasses also keep feature-major copies of keys / values
+
+    def _xenc_pt(self, X, with_tr=False):
         B, P, dx = X.shape
         ch = Chain(B, P, X.device)
         ch.input_rows(X.contiguous(), dx)
         self.x_encoder.append_to(ch).output_pt()
-        return ch.run()[0]
+        if with_tr:
+            ch.store_tr()
+        outs = ch.run()
+        if with_tr:
+            outs[0]._npf_tr = outs[1]  # same activations, [task][feature][point]
+        return outs[0]
 
     def _xyenc_pt(self, X_enc_pt, Y, B, P):
         """Per-point XY encoding (the per-point part of encode_globally) -> PT32 [B, P, r]."""
         ch = Chain(B, P, Y.device)
         ch.input_rows(Y.contiguous(), self.y_dim)
         self.xy_encoder.append_to(ch, x1_pt=X_enc_pt).output_pt()
-        return ch.run()[0]
+        if self._attentive:
+            ch.store_tr()
+        outs = ch.run()
+        if self._attentive:
+            outs[0]._npf_tr = outs[1]
+        return outs[0]
 
     def _head(self, suff, Y_trgt, B, T):
         n_rows = suff.shape[0]
@@ -374,6 +386,7 @@ class AttnCNP(NeuralProcessFamily):
     """Attentive conditional neural process (npf/neuralproc/attnnp.py:27-131)."""
 
     _valid_paths = ["deterministic"]
+    _attentive = True
 
     def __init__(self, x_dim, y_dim, XYEncoder=None, attention="scaledot", attention_kwargs={},
                  self_attention_kwargs={}, is_self_attn=False, **kwargs):
@@ -421,7 +434,8 @@ class AttnCNP(NeuralProcessFamily):
             ch.input_pt(torch.zeros_like(Xt_pt), self.r_dim)
         else:
             ch.input_pt(Xt_pt, self.x_transf_dim)
-            self.attender.append_to(ch, Xc_pt, R, C)
+            self.attender.append_to(ch, Xc_pt, R, C, keys_tr=getattr(Xc_pt, "_npf_tr", None),
+                                        values_tr=getattr(R, "_npf_tr", None))
         self.decoder.append_to(ch, x1_pt=Xt_pt).output_rows()
         return ch.run()[0]
 
@@ -483,7 +497,8 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
                 ch.input_pt(torch.zeros_like(Xt_pt), r)
             else:
                 ch.input_pt(Xt_pt, self.x_transf_dim)
-                self.attender.append_to(ch, Xc_pt, R, C)
+                self.attender.append_to(ch, Xc_pt, R, C, keys_tr=getattr(Xc_pt, "_npf_tr", None),
+                                        values_tr=getattr(R, "_npf_tr", None))
             mod = 0
         else:
             if C == 0:
@@ -491,7 +506,8 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
             else:
                 cha = Chain(B, T, dev, wg_per_task=True)
                 cha.input_pt(Xt_pt, self.x_transf_dim)
-                self.attender.append_to(cha, Xc_pt, R, C).output_pt()
+                self.attender.append_to(cha, Xc_pt, R, C, keys_tr=getattr(Xc_pt, "_npf_tr", None),
+                                        values_tr=getattr(R, "_npf_tr", None)).output_pt()
                 (R_det,) = cha.run()
             ch = Chain(rows, T, dev, wg_per_task=True)
             ch.input_pt(R_det, r, modulus=B)

@@ -62,6 +62,14 @@ def attn_case(name, B, C, T, r):
     prog.linear(v, C, r, mode=CH.L.W_PT_COLS, w_tiles=v.shape[1])
     prog.store_pt(o, r)
     report(name, prog.flops(), timeit(prog._launch))
+    vtr = torch.randn(B, r, CH.pad32(C), device=DEV)
+    prog = CH.Program(B, T, True)
+    prog.load_pt(q, r)
+    prog.linear(k, r, C, mode=CH.L.W_PT_ROWS, w_tiles=k.shape[1])
+    prog.softmax(C, 1 / math.sqrt(r))
+    prog.linear(vtr, C, r, mode=CH.L.W_ROWMAJOR, ldw=vtr.shape[2], w_task_stride=r * vtr.shape[2])
+    prog.store_pt(o, r)
+    report(name + " [values feature-major]", prog.flops(), timeit(prog._launch))
 
 
 def wgrad_case(name, n_tasks, pts, shapes, per_task=False):
