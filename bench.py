@@ -176,6 +176,20 @@ def main():
         ach = fl / sec * 1e-12
         roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
+        # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+        # separate rocprofv3 --pmc passes of this same command), condensed by
+        # tools/summarize_profiles.py into profiles/<round>_summary.json
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+            try:
+                k = json.load(open(f))["kernels"].get("npf::" + name)
+                if k and "hbm_bytes_per_launch" in k and (args.batch, C, T, args.r) == (256, 256, 1024, 256):
+                    roofline["traffic"] = k["hbm_bytes_per_launch"]
+                    roofline["traffic_unit"] = "bytes/launch"
+                    roofline["traffic_source"] = os.path.relpath(f, ROOT)
+                    break
+            except Exception:
+                pass
     elif world > 1 and not args.no_roofline:
         pass
 

@@ -337,6 +337,22 @@ __device__ __forceinline__ float xg_max(float v) {
   return fmaxf(v, __shfl_xor(v, 32));
 }
 
+#ifdef NPF_STAMPS
+// Diagnostic build only (tools/stamp_probe.py): per-phase cycle sums of the slab loop of wave 0
+// of workgroup 0, written to a buffer nothing else reads.
+__device__ unsigned long long g_stamps[8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define NPF_STAMP(i) { const unsigned long long t__ = stamp(); st_sum[i] += t__ - st_last; st_last = t__; }
+#else
+#define NPF_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t g) {
   __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats];
 
@@ -413,6 +429,10 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
   }
   __syncthreads();  // (its vmcnt(0) retires the DMA)
 
+#ifdef NPF_STAMPS
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = stamp();
+#endif
   const float* Z = g_zero16;
   for (int ip = 0; ip < g.n_ops; ++ip) {
     const npf_op_t& o = g.ops[ip];
@@ -429,12 +449,16 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
       // queue (out[] shifts down by one slab per iteration), so the loop body exists once
       // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
       // cache) and no dynamically indexed register array is needed.
+      NPF_STAMP(5)  // everything between LINEAR slab loops (other ops, layer setup)
       for (int nb = 0; nb < NB; ++nb) {
         // 1. start filling the other slot with the next slab (possibly the next layer's)
         if (pf.op < g.n_ops) {
           SlabDma d = dma_begin(pfs, pf.nb, w, smem + (slot ^ 1) * kSlabFloats, !(g.reserved[0] & 1));
+          NPF_STAMP(6)  // loop top
           dma_finish(pfs, d, w);
+          NPF_STAMP(0)  // DMA pieces
           advance();
+          NPF_STAMP(7)  // cursor advance (+ next layer's slab constants)
         }
         // 2. addend tiles (consumed after the barrier)
         f32x4 ad[kBlk];
@@ -449,7 +473,9 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
           if (N - nb * kSlabRows > 16) slab_mfma_any<2>(sl, KB16, w, cur, acc);
           else slab_mfma_any<1>(sl, KB16, w, cur, acc);
         }
+        NPF_STAMP(1)  // addend loads + MFMA loop
         if (!(g.reserved[0] & 4)) __syncthreads();  // slab consumed by all waves; vmcnt(0) lands the next one
+        NPF_STAMP(2)  // barrier (+ wait for the DMA)
         slot ^= 1;
 #pragma unroll
         for (int b = 0; b < kMaxB16 - kBlk; ++b) out[b] = out[b + kBlk];
@@ -468,6 +494,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
           }
           out[kMaxB16 - kBlk + j] = v;
         }
+        NPF_STAMP(3)  // epilogue
       }
       // the layer's blocks now sit at out[16 - 2 NB .. 15]
 #define NPF_TAKE(nbv)                                     \
@@ -597,7 +624,18 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
         for (int s = 0; s < 4; ++s) cur[b][s] = (opc == NPF_OP_RELU) ? fmaxf(cur[b][s], 0.f) : o.f0 * cur[b][s];
     }
   }
+#ifdef NPF_STAMPS
+  NPF_STAMP(5)
+  if (blockIdx.x == 0 && w.tid == 0)
+    for (int i = 0; i < 8; ++i) g_stamps[i] = st_sum[i];
+#endif
 }
+
+#ifdef NPF_STAMPS
+extern "C" int npf_debug_stamps(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static int validate(const npf_program_t* g) {
   if (!g || g->n_ops < 0 || g->n_ops > NPF_MAX_OPS) return NPF_EINVAL;

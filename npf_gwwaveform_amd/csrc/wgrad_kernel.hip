@@ -190,7 +190,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   }
 }
 
-// dW[n][k] (+)= sum_s partial[s][n][k];  db[n] (+)= sum_s partial_db[s][n]
+// dW[n][k] (+)= sum_s partial[s][n][k];  db[n] (+)= sum_s partial_db[s][n].
+// One float4 of the slab per thread, four independent accumulators over the splits (the sum is
+// latency-bound: each term is a separate 16-byte load from a different slab).
 __global__ void wgrad_reduce_kernel(const WgradJobs J, const float* __restrict__ partials) {
   const int j = blockIdx.y;
   const npf_wgrad_job_t& job = J.job[j];
@@ -199,19 +201,33 @@ __global__ void wgrad_reduce_kernel(const WgradJobs J, const float* __restrict__
   const int Np = ((job.N + 31) >> 5) * 32, Kp = ((job.K + 31) >> 5) * 32;
   const size_t slab = (size_t)Np * Kp + Np;
   const float* part = partials + J.part_off[j];
-  const int total = Np * Kp + Np;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int sp = 0; sp < n_split; ++sp) s += part[(size_t)sp * slab + idx];
+  const int total4 = (Np * Kp + Np) >> 2;
+  for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
+    const float* p = part + (size_t)i4 * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int sp = 0;
+    for (; sp + 4 <= n_split; sp += 4) {
+      s0 += *(const f32x4*)(p + (size_t)sp * slab);
+      s1 += *(const f32x4*)(p + (size_t)(sp + 1) * slab);
+      s2 += *(const f32x4*)(p + (size_t)(sp + 2) * slab);
+      s3 += *(const f32x4*)(p + (size_t)(sp + 3) * slab);
+    }
+    for (; sp < n_split; ++sp) s0 += *(const f32x4*)(p + (size_t)sp * slab);
+    const f32x4 s = (s0 + s1) + (s2 + s3);
+    const int idx = i4 * 4;
     if (idx < Np * Kp) {
-      const int n = idx / Kp, k = idx - n * Kp;
-      if (n < job.N && k < job.K) {
+      const int n = idx / Kp, k = idx - n * Kp;  // Kp % 4 == 0: the float4 stays inside row n
+      if (n < job.N) {
         float* d = job.dW + (size_t)n * job.ldw + k;
-        *d = job.accumulate ? *d + s : s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < job.K) d[e] = job.accumulate ? d[e] + s[e] : s[e];
       }
     } else if (job.db) {
       const int n = idx - Np * Kp;
-      if (n < job.N) job.db[n] = job.accumulate ? job.db[n] + s : s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < job.N) job.db[n + e] = job.accumulate ? job.db[n + e] + s[e] : s[e];
     }
   }
 }
@@ -292,7 +308,7 @@ extern "C" int npf_wgrad_run(const npf_wgrad_job_t* jobs, int32_t n_jobs, int32_
   hipLaunchKernelGGL(npf::wgrad_kernel, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);
   NPF_CHECK_LAUNCH();
   if (any_shared) {
-    hipLaunchKernelGGL(npf::wgrad_reduce_kernel, dim3(64, n_jobs), dim3(256), 0, (hipStream_t)stream, J,
+    hipLaunchKernelGGL(npf::wgrad_reduce_kernel, dim3(65, n_jobs), dim3(256), 0, (hipStream_t)stream, J,
                        (const float*)partials);
     NPF_CHECK_LAUNCH();
   }

@@ -98,6 +98,9 @@ if __name__ == "__main__":
         chain_case("32->256 then 7 x 256->256", B, T, [(32, 256)] + [(256, 256)] * 7)
         chain_case("8 x [256->32]", B, T, [(256, 32), (32, 256)] * 4)
         chain_case("8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+    if "occ" in which:
+        for nt in (8, 16, 32, 64, 128):
+            chain_case(f"occupancy probe: {nt * 1024 // 64} WGs, 8 x linear 256->256", nt, 1024, [(256, 256)] * 8)
     if "ablate" in which:
         for bits, name in [(0, "full"), (1, "no slab DMA"), (2, "no bias loads"), (4, "no barrier"), (8, "no MFMA"),
                            (9, "no MFMA, no DMA"), (15, "nothing"), (16, "no start skew")]:
