@@ -47,7 +47,8 @@ extern "C" {
 #define NPF_ELAUNCH (-2)  /* hipLaunch failed (hipGetLastError != 0)    */
 
 #define NPF_MAX_OPS 40
-#define NPF_MAX_FEATURES 256 /* widest activation a chain keeps in registers */
+#define NPF_MAX_FEATURES 512 /* widest activation a chain keeps in registers (programs that stay
+                                <= 256 wide run the 2-workgroups-per-CU variant of the kernel) */
 
 /* ---- chain programs ------------------------------------------------------------- */
 enum npf_opcode {

@@ -15,7 +15,8 @@ import torch
 from . import _build
 
 NPF_MAX_OPS = 40
-NPF_MAX_FEATURES = 256
+NPF_MAX_FEATURES = 512        # widest layer side of a chain (inference)
+NPF_MAX_TRAIN_FEATURES = 256  # widest layer side with a backward pass (npf_wgrad_run)
 
 # opcodes (enum npf_opcode)
 OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFTMAX, OP_ADD_PT, OP_MASK_POS, \

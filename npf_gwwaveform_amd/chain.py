@@ -264,8 +264,9 @@ class Chain:
         lets the backward pass stream K^T by LDS-DMA."""
         if not self.wg_per_task:
             raise ValueError("attention needs wg_per_task=True")
-        if n_keys > L.NPF_MAX_FEATURES:
-            raise NotImplementedError(f"more than {L.NPF_MAX_FEATURES} context points per task are not supported yet")
+        if n_keys > L.NPF_MAX_TRAIN_FEATURES:
+            raise NotImplementedError(
+                f"more than {L.NPF_MAX_TRAIN_FEATURES} context points per task are not supported yet")
         self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F, "tr": keys_tr}))
         self.F = n_keys
         return self
@@ -315,6 +316,12 @@ class _ChainFn(torch.autograd.Function):
         if not chain.grad_enabled:
             needs_grad = [False] * len(needs_grad)
         train = any(needs_grad)  # (grad mode is always off inside Function.forward)
+        if train:
+            for st in chain.steps:
+                if st.kind == "linear" and max(st.a["N"], st.a["K"]) > L.NPF_MAX_TRAIN_FEATURES:
+                    raise NotImplementedError(
+                        f"training through a {st.a['K']}->{st.a['N']} layer: the backward kernels handle at most "
+                        f"{L.NPF_MAX_TRAIN_FEATURES} features per side (inference works up to {L.NPF_MAX_FEATURES})")
         prog = Program(chain.n_tasks, chain.pts, chain.wg_per_task)
         dev = chain.device
         T = [t.detach() if t is not None else None for t in chain.tensors]

@@ -32,10 +32,12 @@ namespace npf {
 constexpr int kWaves = 4;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kTilesPerWG = 2;
-constexpr int kMaxB16 = NPF_MAX_FEATURES / 16;  // 16-feature blocks a wave keeps in registers
+// The kernel exists in two widths (template parameter MAXB = 16-feature blocks a wave keeps in
+// registers): 16 (<= 256 features, 2 workgroups per CU) and 32 (<= 512 features, e.g. the
+// r = 512 decode-only configuration: 128 + 128 activation registers, one workgroup per CU).
 constexpr int kSlabRows = 32;
 constexpr int kBlk = kSlabRows / 16;            // 16-row output blocks (accumulators) per slab
-constexpr int kSlabFloats = kSlabRows * NPF_MAX_FEATURES + 64;  // rows, then the 64 biases
+constexpr int slab_floats(int maxb) { return kSlabRows * 16 * maxb + 64; }  // rows, then the biases
 constexpr int kSlots = 2;
 
 struct Wave {
@@ -81,9 +83,9 @@ struct SlabOp {
   int mode, ldw, Fq, n_slabs;
   bool vec16;
   // fast path (16-byte pieces, power-of-two row length, no column padding): piece number i
-  // of a wave reads  base(slab) + i * step + lo[i & 3]
+  // of a wave reads  base(slab) + i * step + lo[i & 7]
   bool fast;
-  int lo[4];        // per-lane source offsets (floats), one per piece phase
+  int lo[8];        // per-lane source offsets (floats), one per piece phase
   int step;         // scalar source advance between a wave's consecutive pieces (floats)
   int slab_stride;  // scalar source advance between consecutive slabs (floats)
   int n_pw;         // pieces per wave per slab
@@ -116,25 +118,25 @@ __device__ __forceinline__ SlabOp make_slab_op(const npf_op_t& o, int task) {
   return s;
 }
 
-// Lane offsets of the fast DMA path.  Piece q = wave + 4 i covers linear chunks
-// [64 q, 64 q + 64) of the slab image: rows q*rpp .. (rpp = 64 / cpr rows per piece).  The
-// swizzle only depends on the low 4 bits of the row, which repeat every 4 pieces of a wave.
+// Lane offsets of the fast DMA path.  Piece q = wave + 4 i covers linear chunks [64 q, 64 q + 64)
+// of the slab image: rows q*rpp .. (rpp = 64 / cpr rows per piece) or, for rows longer than a
+// piece (cpr = 128), half of row q / 2.  The swizzle only depends on the low 4 bits of the row,
+// which repeat every 4 (8 for cpr = 128) pieces of a wave.
 __device__ __forceinline__ void slab_fast_setup(SlabOp& s, const Wave& w) {
   s.fast = s.vec16 && s.lcpr >= 0 && s.K == s.Kp && s.mode != NPF_W_PT_COLS;
   s.n_pw = s.Kp >> 5;  // (32 rows * Kp * 4 B / 1 KiB) / 4 waves
   if (!s.fast) return;
-  const int rpp = 64 >> s.lcpr;             // rows per piece (1, 2, 4, 8)
-  const int lr = w.lane >> s.lcpr;           // row of this lane inside the piece
-  const int cpos = w.lane & (s.cpr - 1);     // chunk position inside the row
-  const int rstride = (s.mode == NPF_W_ROWMAJOR) ? s.ldw : 4;  // floats per matrix row step
+  const int rstride = (s.mode == NPF_W_ROWMAJOR) ? s.ldw : 4;      // floats per matrix row step
+  const int cstride = (s.mode == NPF_W_ROWMAJOR) ? 4 : 128;        // floats per chunk step
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int row = (w.wave + 4 * v) * rpp + lr;  // row inside the slab (its low 4 bits are what matters)
+  for (int v = 0; v < 8; ++v) {
+    const int lin = (w.wave + 4 * v) * 64 + w.lane;   // linear chunk of piece v of this wave
+    const int row = lin >> s.lcpr, cpos = lin & (s.cpr - 1);
     const int ch = cpos ^ (row & s.swz);
-    s.lo[v] = (s.mode == NPF_W_ROWMAJOR) ? (w.wave * rpp + lr) * rstride + ch * 4
-                                          : (w.wave * rpp + lr) * 4 + ch * 128;
+    // offset relative to the source of piece v = slab base + v * step (step: see below)
+    s.lo[v] = row * rstride + ch * cstride - v * (((4 * 64) >> s.lcpr) * rstride);
   }
-  s.step = 4 * rpp * rstride;
+  s.step = ((4 * 64) >> s.lcpr) * rstride;  // 4 pieces further = this many rows further
   s.slab_stride = (s.mode == NPF_W_ROWMAJOR) ? kSlabRows * s.ldw : s.Kp * 32;
 }
 
@@ -215,8 +217,8 @@ __device__ __forceinline__ void dma_finish(const SlabOp& s, SlabDma& d, const Wa
     const float* base = s.W + (size_t)(d.row0 / kSlabRows) * s.slab_stride;
     float* dst = d.slot + w.wave * 256;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < s.n_pw) dma16(base + (size_t)(i * s.step) + s.lo[i & 3], dst + i * (kWaves * 256));
+    for (int i = 0; i < 16; ++i)
+      if (i < s.n_pw) dma16(base + (size_t)(i * s.step) + s.lo[i & 7], dst + i * (kWaves * 256));
     d.q = d.n_instr;
   }
   while (d.q < d.n_instr) dma_piece(s, d, w);
@@ -234,8 +236,8 @@ __device__ __forceinline__ void dma_finish(const SlabOp& s, SlabDma& d, const Wa
 // KB16S > 0: the number of 16-feature input blocks is a compile-time constant (straight-line
 // code: hipcc hoists the LDS reads of later blocks above the MFMAs of earlier ones, which
 // hides the LDS latency inside one wave); KB16S == 0: runtime count with a guard per block.
-template <int NBLK, int KB16S>
-__device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wave& w, const f32x4 (&cur)[kMaxB16],
+template <int NBLK, int KB16S, int MAXB>
+__device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wave& w, const f32x4 (&cur)[MAXB],
                                           f32x4 (&acc)[kBlk]) {
   if (KB16S > 0) KB16 = KB16S;
   const int Kp = KB16 * 16;
@@ -299,7 +301,7 @@ __device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wav
 #undef NPF_LAST
   } else {
 #pragma unroll
-    for (int kb = 0; kb < kMaxB16; ++kb) {
+    for (int kb = 0; kb < MAXB; ++kb) {
       if (kb < KB16) {
         const int off = (((4 * kb + w.g) ^ ps) << 2);
         f32x4 x[NBLK];
@@ -315,15 +317,21 @@ __device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wav
   }
 }
 
-template <int NBLK>
-__device__ __forceinline__ void slab_mfma_any(const float* slot, int KB16, const Wave& w,
-                                              const f32x4 (&cur)[kMaxB16], f32x4 (&acc)[kBlk]) {
+template <int NBLK, int MAXB>
+__device__ __forceinline__ void slab_mfma_any(const float* slot, int KB16, const Wave& w, const f32x4 (&cur)[MAXB],
+                                              f32x4 (&acc)[kBlk]) {
+  if constexpr (MAXB >= 32) {
+    if (KB16 == 32) {
+      slab_mfma<NBLK, 32, MAXB>(slot, KB16, w, cur, acc);
+      return;
+    }
+  }
   switch (KB16) {
-    case 16: slab_mfma<NBLK, 16>(slot, KB16, w, cur, acc); break;
-    case 8: slab_mfma<NBLK, 8>(slot, KB16, w, cur, acc); break;
-    case 4: slab_mfma<NBLK, 4>(slot, KB16, w, cur, acc); break;
-    case 2: slab_mfma<NBLK, 2>(slot, KB16, w, cur, acc); break;
-    default: slab_mfma<NBLK, 0>(slot, KB16, w, cur, acc); break;
+    case 16: slab_mfma<NBLK, 16, MAXB>(slot, KB16, w, cur, acc); break;
+    case 8: slab_mfma<NBLK, 8, MAXB>(slot, KB16, w, cur, acc); break;
+    case 4: slab_mfma<NBLK, 4, MAXB>(slot, KB16, w, cur, acc); break;
+    case 2: slab_mfma<NBLK, 2, MAXB>(slot, KB16, w, cur, acc); break;
+    default: slab_mfma<NBLK, 0, MAXB>(slot, KB16, w, cur, acc); break;
   }
 }
 
@@ -353,7 +361,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define NPF_STAMP(i)
 #endif
 
-__global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t g) {
+template <int MAXB>
+__global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(const npf_program_t g) {
+  constexpr int kMaxB16 = MAXB;
+  constexpr int kSlabFloats = slab_floats(MAXB);
   __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats];
 
   Wave w;
@@ -470,8 +481,8 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
         for (int j = 0; j < kBlk; ++j) acc[j] = zero4;
         const float* sl = smem + slot * kSlabFloats;
         if (!(g.reserved[0] & 8)) {
-          if (N - nb * kSlabRows > 16) slab_mfma_any<2>(sl, KB16, w, cur, acc);
-          else slab_mfma_any<1>(sl, KB16, w, cur, acc);
+          if (N - nb * kSlabRows > 16) slab_mfma_any<2, MAXB>(sl, KB16, w, cur, acc);
+          else slab_mfma_any<1, MAXB>(sl, KB16, w, cur, acc);
         }
         NPF_STAMP(1)  // addend loads + MFMA loop
         if (!(g.reserved[0] & 4)) __syncthreads();  // slab consumed by all waves; vmcnt(0) lands the next one
@@ -497,17 +508,13 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const npf_program_t 
         NPF_STAMP(3)  // epilogue
       }
       // the layer's blocks now sit at out[16 - 2 NB .. 15]
-#define NPF_TAKE(nbv)                                     \
-  case nbv:                                               \
-    _Pragma("unroll") for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv]; \
-    break;
-      switch (NB) {
-        NPF_TAKE(1) NPF_TAKE(2) NPF_TAKE(3) NPF_TAKE(4) NPF_TAKE(5) NPF_TAKE(6) NPF_TAKE(7)
-        default:
+      // (one unrolled copy per possible NB keeps every register index static)
 #pragma unroll
-          for (int b = 0; b < kMaxB16; ++b) cur[b] = out[b];
-      }
-#undef NPF_TAKE
+      for (int nbv = 1; nbv <= kMaxB16 / kBlk; ++nbv)
+        if (NB == nbv) {
+#pragma unroll
+          for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv];
+        }
     } else if (opc == NPF_OP_LOAD_PT || opc == NPF_OP_ADD_PT || opc == NPF_OP_MASK_POS || opc == NPF_OP_ROWDOT_PT ||
                opc == NPF_OP_SOFTMAX_BWD) {
       const int FB = o.i0 >> 4;
@@ -708,7 +715,19 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
   else
     grid = ((long)g.n_tasks * g.tiles_per_task + npf::kTilesPerWG - 1) / npf::kTilesPerWG;
   if (grid <= 0 || grid > 0x7fffffffL) return NPF_EINVAL;
-  hipLaunchKernelGGL(npf::chain_kernel, dim3((unsigned)grid), dim3(npf::kThreads), 0, (hipStream_t)stream, g);
+  bool wide = false;
+  for (int i = 0; i < g.n_ops; ++i) {
+    const npf_op_t& o = g.ops[i];
+    const bool feat_op = o.op == NPF_OP_LOAD_PT || o.op == NPF_OP_STORE_PT || o.op == NPF_OP_ADD_PT ||
+                         o.op == NPF_OP_MASK_POS || o.op == NPF_OP_ROWDOT_PT || o.op == NPF_OP_SOFTMAX_BWD ||
+                         o.op == NPF_OP_ADD_TASKVEC || o.op == NPF_OP_SOFTMAX || o.op == NPF_OP_STORE_TR;
+    if (o.op == NPF_OP_LINEAR && (o.i0 > 256 || o.i1 > 256)) wide = true;
+    if (feat_op && o.i0 > 256) wide = true;
+  }
+  if (wide)
+    hipLaunchKernelGGL(npf::chain_kernel<32>, dim3((unsigned)grid), dim3(npf::kThreads), 0, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(npf::chain_kernel<16>, dim3((unsigned)grid), dim3(npf::kThreads), 0, (hipStream_t)stream, g);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

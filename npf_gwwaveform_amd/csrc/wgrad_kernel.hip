@@ -19,7 +19,8 @@ namespace npf {
 
 constexpr int kWgThreads = 1024;
 constexpr int kWgWaves = kWgThreads / 64;
-constexpr int kQRows = NPF_MAX_FEATURES / 4;  // 64 quad rows per operand
+constexpr int kWgMaxF = 256;            // widest layer side this kernel handles
+constexpr int kQRows = kWgMaxF / 4;     // 64 quad rows per operand
 constexpr int kMaxJobs = 16;
 
 struct WgradJobs {
@@ -238,7 +239,7 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
   int n_shared = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const npf_wgrad_job_t& b = jobs[j];
-    if (!b.dZ || !b.A || !b.dW || b.N <= 0 || b.K <= 0 || b.N > NPF_MAX_FEATURES || b.K > NPF_MAX_FEATURES) return NPF_EINVAL;
+    if (!b.dZ || !b.A || !b.dW || b.N <= 0 || b.K <= 0 || b.N > npf::kWgMaxF || b.K > npf::kWgMaxF) return NPF_EINVAL;
     if ((((uintptr_t)b.dZ) | ((uintptr_t)b.A)) & 15) return NPF_EINVAL;
     if (b.per_task && (((uintptr_t)b.dW) & 15)) return NPF_EINVAL;
     if (!b.per_task && b.ldw < b.K) return NPF_EINVAL;

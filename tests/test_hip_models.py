@@ -133,3 +133,46 @@ def test_unknown_paths_raise_like_reference():
         A.CNP(1, 1, encoded_path="nope")
     with pytest.raises(ValueError, match="Unknown attention"):
         A.get_attender("nope", 8, 8, 8)
+
+
+def test_decode_only_r512_matches_reference():
+    """BASELINE config 5 shape at reduced batch: decode(X_trgt_enc, R_trgt) with a 512-wide,
+    4-layer decoder and 4096 targets (base.py:327-367) -- the <= 512-feature variant of the chain
+    kernel -- against the reference's output (tests/golden/g5_decode_r512.npz)."""
+    import warnings
+    from functools import partial
+
+    import npf_gwwaveform_amd as A
+
+    g = specs.load_golden("g5_decode_r512")
+    cfg, dparams = specs.make_decode_params()
+    inp = specs.make_decode_inputs()
+    case = specs.DECODE_CASE
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = A.CNP(case["dx"], case["dy"], r_dim=case["r"],
+                      Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=case["L_dec"], hidden_size=case["r"]),
+                                                 is_sum_merge=True))
+    sd = model.state_dict()
+    sd.update(dparams)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        p = model.decode(inp["X_trgt_enc"].to(DEV), inp["R_trgt"].to(DEV))
+    assert_close(p.base_dist.loc, g["loc"], what="decode r512 loc")
+    assert_close(p.base_dist.scale, g["scale"], what="decode r512 scale")
+    np.testing.assert_allclose(p.base_dist.scale.cpu().numpy(), g["scale"], rtol=1e-5)
+
+
+def test_training_wider_than_256_is_refused_loudly():
+    import npf_gwwaveform_amd as A
+
+    m = A.MLP(512, 512, hidden_size=512).to(DEV)
+    x = torch.randn(64, 512, device=DEV, requires_grad=True)
+    with pytest.raises(NotImplementedError, match="backward kernels"):
+        m(x)
+    with torch.no_grad():
+        y = m(x)
+    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, m.to_hidden.weight, m.to_hidden.bias)),
+                                     m.out.weight, m.out.bias)
+    assert_close(y, ref, what="512-wide MLP inference")

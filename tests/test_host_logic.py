@@ -177,7 +177,7 @@ def test_chain_description_and_flop_count():
     with pytest.raises(ValueError):
         ch.linear(torch.zeros(8, 5), None)  # wrong fan-in
     with pytest.raises(NotImplementedError):
-        Chain(1, 8, "cpu").input_pt(torch.zeros(1), 256).linear(torch.zeros(512, 256), None)
+        Chain(1, 8, "cpu").input_pt(torch.zeros(1), 256).linear(torch.zeros(1024, 256), None)
     with pytest.raises(ValueError):
         Chain(1, 8, "cpu").input_pt(torch.zeros(1), 8).attn_scores(torch.zeros(1), 4)  # needs wg_per_task
     p = Program(3, 70, False)

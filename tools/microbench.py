@@ -98,6 +98,9 @@ if __name__ == "__main__":
         chain_case("32->256 then 7 x 256->256", B, T, [(32, 256)] + [(256, 256)] * 7)
         chain_case("8 x [256->32]", B, T, [(256, 32), (32, 256)] * 4)
         chain_case("8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+    if "decode" in which:
+        # BASELINE config 5 per GPU: decoder r=512, L=4, T=4096, 512 tasks (4096 / 8 GPUs)
+        chain_case("decode c5: 6 x 512->512 + 512->4, B=128 T=4096", 128, 4096, [(512, 512)] * 6 + [(512, 4)])
     if "occ" in which:
         for nt in (8, 16, 32, 64, 128):
             chain_case(f"occupancy probe: {nt * 1024 // 64} WGs, 8 x linear 256->256", nt, 1024, [(256, 256)] * 8)
