@@ -87,7 +87,15 @@ class MLP(nn.Module):
     def append_to(self, ch: Chain, first_addend=None, first_addend_modulus=0) -> Chain:
         ls = self.layers()
         for j, lin in enumerate(ls):
-            ch.linear(lin.weight, lin.bias, relu=(j < len(ls) - 1))
+            W = lin.weight
+            if j == 0 and W.shape[1] % 4 != 0 and W.shape[1] == ch.F:
+                # skinny first layers (x: 1-2 features, y: 2): zero-pad the fan-in to a multiple of 4
+                # so that the weight rows are 16-byte aligned and stream through the 16-byte LDS-DMA
+                # path (the padded input features are zero, so the result is unchanged)
+                pad = -W.shape[1] % 4
+                W = torch.nn.functional.pad(W, (0, pad))
+                ch.F = W.shape[1]
+            ch.linear(W, lin.bias, relu=(j < len(ls) - 1))
         return ch
 
     def forward(self, x):
