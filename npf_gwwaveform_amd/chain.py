@@ -13,6 +13,7 @@ Tensors between chains are "PT32" tensors: ``[n_tasks, tiles, F/4, 32, 4]`` fp32
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -25,6 +26,8 @@ from . import _lib as L
 # entries are (kernel, algorithmic flops, start event, end event)
 PROFILE = None
 DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microbench.py)
+# tests / tools: 1 = 64-point workgroups, 2 = 128-point (paired) workgroups, 0 = the library's choice
+FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 
 
 def pad32(n: int) -> int:
@@ -140,6 +143,7 @@ class Program:
         prog.n_tasks, prog.pts_per_task, prog.tiles_per_task = self.n_tasks, self.pts, tiles_of(self.pts)
         prog.wg_per_task = int(self.wg_per_task)
         prog.reserved[0] = DEBUG_ABLATE
+        prog.reserved[1] = FORCE_WG
         for i, o in enumerate(self.ops):
             prog.ops[i] = o
         L.check(L.load().npf_chain_run(C.byref(prog), L.stream_ptr()), "npf_chain_run")

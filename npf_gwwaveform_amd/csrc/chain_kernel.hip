@@ -29,16 +29,22 @@
 
 namespace npf {
 
-constexpr int kWaves = 4;
-constexpr int kThreads = 64 * kWaves;
-constexpr int kTilesPerWG = 2;
+constexpr int kWaves = 4;  // waves that issue the slab DMA (the first four of a workgroup)
+// Workgroup shapes (template parameter WAVES of the kernel):
+//   4 waves = 64 points, 2-slot slab ring, two workgroups per CU that drift against each other;
+//   8 waves = 128 points = two *phase groups* of 4 waves (one wave of each group per SIMD), one
+//     workgroup per CU, 3-slot ring.  Group A (waves 0-3) streams the slabs and is one slab
+//     ahead; group B (waves 4-7) only consumes.  Their barriers sit at different places of the
+//     slab loop (A: after the MFMAs, B: before them), so inside one barrier interval A runs
+//     epilogue -> DMA issue -> MFMAs while B runs MFMAs -> epilogue: one wave's scalar/VALU/DMA
+//     phase always meets the MFMAs of the other wave of its SIMD, and every weight slab is
+//     fetched once per 128 points instead of once per 64.
 // The kernel exists in two widths (template parameter MAXB = 16-feature blocks a wave keeps in
 // registers): 16 (<= 256 features, 2 workgroups per CU) and 32 (<= 512 features, e.g. the
 // r = 512 decode-only configuration: 128 + 128 activation registers, one workgroup per CU).
 constexpr int kSlabRows = 32;
 constexpr int kBlk = kSlabRows / 16;            // 16-row output blocks (accumulators) per slab
 constexpr int slab_floats(int maxb) { return kSlabRows * 16 * maxb + 64; }  // rows, then the biases
-constexpr int kSlots = 2;
 
 struct Wave {
   int tid, lane, wave;     // wave is wave-uniform (readfirstlane)
@@ -74,6 +80,7 @@ __device__ __forceinline__ const float* pt_lane(const void* base, const npf_prog
 // LDS-DMA makes hipcc drain vmcnt(0) at unrelated places (cdna guide 5, trap (b)).
 // Out-of-range rows / columns are fetched from a 16-byte zero buffer.
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_zero128[32] = {};  // "no bias" source of the fast path
 
 // Per-LINEAR constants of the slab stream (all wave-uniform).
 struct SlabOp {
@@ -85,7 +92,7 @@ struct SlabOp {
   // fast path (16-byte pieces, power-of-two row length, no column padding): piece number i
   // of a wave reads  base(slab) + i * step + lo[i & 7]
   bool fast;
-  int lo[8];        // per-lane source offsets (floats), one per piece phase
+  unsigned lo[8];   // per-lane source offsets (bytes, >= 0), one per piece phase
   int step;         // scalar source advance between a wave's consecutive pieces (floats)
   int slab_stride;  // scalar source advance between consecutive slabs (floats)
   int n_pw;         // pieces per wave per slab
@@ -134,7 +141,8 @@ __device__ __forceinline__ void slab_fast_setup(SlabOp& s, const Wave& w) {
     const int row = lin >> s.lcpr, cpos = lin & (s.cpr - 1);
     const int ch = cpos ^ (row & s.swz);
     // offset relative to the source of piece v = slab base + v * step (step: see below)
-    s.lo[v] = row * rstride + ch * cstride - v * (((4 * 64) >> s.lcpr) * rstride);
+    // (row advances by exactly (256 >> lcpr) per piece phase, so the difference is row(0) * rstride >= 0)
+    s.lo[v] = 4u * (unsigned)(row * rstride + ch * cstride - v * (((4 * 64) >> s.lcpr) * rstride));
   }
   s.step = ((4 * 64) >> s.lcpr) * rstride;  // 4 pieces further = this many rows further
   s.slab_stride = (s.mode == NPF_W_ROWMAJOR) ? kSlabRows * s.ldw : s.Kp * 32;
@@ -148,6 +156,11 @@ struct SlabCursor {
 __device__ __forceinline__ void dma16(const float* src, float* lds_dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+// uniform 64-bit base + 32-bit unsigned lane offset: selects the SGPR-base form of the
+// instruction (global_load_lds_dwordx4 v_off, s[base:base+1]) -- no VALU address arithmetic
+__device__ __forceinline__ void dma16_so(const char* uniform_base, unsigned lane_off, float* lds_dst_wave_uniform) {
+  dma16((const float*)(uniform_base + (size_t)lane_off), lds_dst_wave_uniform);
 }
 __device__ __forceinline__ void dma4(const float* src, float* lds_dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -210,22 +223,48 @@ __device__ __forceinline__ void dma_piece(const SlabOp& s, SlabDma& d, const Wav
   d.q += kWaves;
 }
 
+__device__ __forceinline__ void dma4_so(const char* uniform_base, unsigned lane_off, float* lds_dst_wave_uniform) {
+  // (the empty asm keeps the 32-bit offset in this basic block: hoisted out of a loop, its
+  // zero-extension becomes a 64-bit VGPR pair and instruction selection falls back to a VALU add)
+  asm volatile("" : "+v"(lane_off));
+  dma4((const float*)(uniform_base + (size_t)lane_off), lds_dst_wave_uniform);
+}
+// A full slab on the fast path: one SALU add + one DMA instruction per 1 KiB piece.  The
+// lane-offset registers lo[] live for the whole layer: hipcc waits for vmcnt(0) before it
+// overwrites a VGPR that an in-flight LDS-DMA instruction used as its address, so any
+// per-piece address arithmetic in VGPRs serialises the wave behind its own DMA.
+// NPW > 0: compile-time piece count.
+template <int NPW>
+__device__ __forceinline__ void dma_fast_slab(const SlabOp& s, int nb, float* slot, const Wave& w) {
+  const char* base = (const char*)(s.W + (size_t)nb * s.slab_stride);
+  float* dst = slot + w.wave * 256;
+#pragma unroll
+  for (int i = 0; i < (NPW > 0 ? NPW : 16); ++i)
+    if (NPW > 0 || i < s.n_pw) dma16_so(base + (size_t)(i * s.step) * 4, s.lo[i & 7], dst + i * (kWaves * 256));
+}
+// the 32 biases of a full slab (fast path): wave 0, lanes 32..63 re-read the first 32
+__device__ __forceinline__ void dma_fast_bias(const SlabOp& s, int row0, float* slot, const Wave& w) {
+  if (w.wave == 0) {
+    const char* base = s.bias != nullptr ? (const char*)(s.bias + row0) : (const char*)g_zero128;
+    dma4_so(base, (unsigned)(w.lane & 31) * 4u, slot + kSlabRows * s.Kp);
+  }
+}
+__device__ __forceinline__ void dma_bias(const SlabOp& s, int row0, float* slot, const Wave& w) {
+  if (w.wave == 0) {
+    const int n = row0 + w.lane;
+    dma4((s.bias != nullptr && w.lane < kSlabRows && n < s.N) ? s.bias + n : g_zero16, slot + kSlabRows * s.Kp);
+  }
+}
+
 // the rest of the slab's pieces + the 64 biases of its rows
 __device__ __forceinline__ void dma_finish(const SlabOp& s, SlabDma& d, const Wave& w) {
   if (d.on && s.fast && d.row0 + kSlabRows <= s.N) {
     // full slab on the fast path: ~6 instructions per 1 KiB piece
-    const float* base = s.W + (size_t)(d.row0 / kSlabRows) * s.slab_stride;
-    float* dst = d.slot + w.wave * 256;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (i < s.n_pw) dma16(base + (size_t)(i * s.step) + s.lo[i & 7], dst + i * (kWaves * 256));
+    dma_fast_slab<0>(s, d.row0 / kSlabRows, d.slot, w);
     d.q = d.n_instr;
   }
   while (d.q < d.n_instr) dma_piece(s, d, w);
-  if (d.on && w.wave == 0) {
-    const int n = d.row0 + w.lane;
-    dma4((s.bias != nullptr && w.lane < kSlabRows && n < s.N) ? s.bias + n : g_zero16, d.slot + kSlabRows * s.Kp);
-  }
+  if (d.on) dma_bias(s, d.row0, d.slot, w);
 }
 
 // One 32-row slab = two 16-row output blocks (independent accumulator chains):
@@ -260,9 +299,13 @@ __device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wav
 #pragma unroll
     for (int t = 0; t < 4; ++t) addr[t] = lds0 + (((t ^ (ps >> 2)) << 6) | ((w.g ^ (ps & 3)) << 4));
     constexpr int kRowBlk = 16 * KB16S * 16 * 4;  // bytes between output blocks j (16 rows)
-    f32x4 fr[2][NBLK];
+    f32x4 fr[2][NBLK] = {};
     // one statement = wait for the current fragments + issue the next ones: the "+v" operands
     // make the MFMAs of the block depend on it, so nothing can be scheduled around the wait
+#ifdef NPF_EXP_NOLDS  // diagnostic build: same MFMA stream without the LDS fragment reads (results are garbage)
+#define NPF_STEP(curf, nxtf, kbn) asm volatile("s_nop 0" : "+v"(nxtf[0]), "+v"(nxtf[NBLK - 1]), "+v"(curf[0]), "+v"(curf[NBLK - 1]));
+#define NPF_LAST(curf) asm volatile("s_nop 0" : "+v"(curf[0]), "+v"(curf[NBLK - 1]));
+#else
 #define NPF_STEP(curf, nxtf, kbn)                                                                          \
   if constexpr (NBLK == 2)                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6" \
@@ -277,6 +320,7 @@ __device__ __forceinline__ void slab_mfma(const float* slot, int KB16, const Wav
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(curf[0]), "+v"(curf[1]));                  \
   else                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(curf[0]));
+#endif
     // prologue: fragments of block 0
     if constexpr (NBLK == 2)
       asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:%3"
@@ -348,7 +392,7 @@ __device__ __forceinline__ float xg_max(float v) {
 #ifdef NPF_STAMPS
 // Diagnostic build only (tools/stamp_probe.py): per-phase cycle sums of the slab loop of wave 0
 // of workgroup 0, written to a buffer nothing else reads.
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[16];  // wave 0 (group A), wave 4 (group B, paired variant)
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -361,10 +405,13 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define NPF_STAMP(i)
 #endif
 
-template <int MAXB>
-__global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(const npf_program_t g) {
+template <int MAXB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) void chain_kernel(const npf_program_t g) {
   constexpr int kMaxB16 = MAXB;
   constexpr int kSlabFloats = slab_floats(MAXB);
+  constexpr int kTilesPerWG = WAVES / 2;
+  constexpr bool kPaired = WAVES == 8;
+  constexpr int kSlots = kPaired ? 3 : 2;
   __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats];
 
   Wave w;
@@ -375,6 +422,8 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
   w.wave = __builtin_amdgcn_readfirstlane(w.tid >> 6);
   w.half = w.wave & 1;
   const int wtile = w.wave >> 1;
+  const bool grp_b = kPaired && w.wave >= kWaves;  // wave-uniform: the consuming phase group
+  const bool issuer = !grp_b;
   if (g.wg_per_task) {
     const int wgs = (g.tiles_per_task + kTilesPerWG - 1) / kTilesPerWG;
     w.task = blockIdx.x / wgs;
@@ -396,7 +445,7 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
   // they would stay in lockstep (equal MFMA arbitration keeps them aligned) and idle the
   // matrix pipe during every per-slab scalar phase.  Delay the one in the odd wave slot by
   // about half a slab period so that one workgroup's scalar phase meets the other's MFMAs.
-  if (!(g.reserved[0] & 16)) {
+  if (!kPaired && !(g.reserved[0] & 16)) {
     const unsigned wave_slot = __builtin_amdgcn_s_getreg(6148);  // HW_REG_HW_ID[3:0] = WAVE_ID
     if (wave_slot & 1) __builtin_amdgcn_s_sleep(40);
   }
@@ -431,7 +480,8 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
       seek();
     }
   };
-  seek();
+  if (issuer) seek();
+  else pf.op = g.n_ops;
   int slot = 0;
   if (pf.op < g.n_ops) {  // prologue: slab 0 of the first LINEAR
     SlabDma d0 = dma_begin(pfs, pf.nb, w, smem, true);
@@ -456,15 +506,81 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
       const bool add = ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid;
       const float* addt = add ? pt_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4) : Z;
       const int astep = add ? 128 : 0;  // (no addend: every load reads the zero buffer)
-      // Runtime slab loop with *static* register indices: finished blocks enter a register
+      NPF_STAMP(5)  // everything between LINEAR slab loops (other ops, layer setup)
+      // Fast path for the 256 -> 256 layers (all the heavy ones at r = 256, attention included):
+      // the 8 slab steps are unrolled, so the epilogue writes the slab's own two output blocks
+      // (static registers), the slab DMA is one SALU add + one instruction per piece, and the
+      // cursor logic runs once per layer.  While the sibling wave of the SIMD is inside its
+      // MFMA loop every VALU instruction of this wave waits for an fp32 MFMA to drain (~32
+      // cycles), so what counts outside the MFMA loop is the number of VALU instructions.
+      bool fast_layer = false;
+      if constexpr (MAXB == 16)
+        fast_layer = KB16 == 16 && N == 256 && g.reserved[0] == 0 && (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast));
+      if (fast_layer) {
+#pragma unroll
+        for (int I = 0; I < 8; ++I) {
+          if (issuer) {
+            float* nslot = smem + (kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1)) * kSlabFloats;
+            if (I < 7) {
+              dma_fast_slab<8>(pfs, I + 1, nslot, w);
+              dma_fast_bias(pfs, (I + 1) * kSlabRows, nslot, w);
+              if (I == 6) {
+                pf.nb = 7;
+                advance();  // on to the next LINEAR's constants
+              }
+            } else if (pf.op < g.n_ops) {
+              SlabDma d = dma_begin(pfs, pf.nb, w, nslot, true);
+              dma_finish(pfs, d, w);
+              advance();
+            }
+            NPF_STAMP(0)
+          }
+          const float* sl = smem + slot * kSlabFloats;
+          if (grp_b) {
+            NPF_STAMP(6)
+            __syncthreads();
+            NPF_STAMP(4)
+          }
+          f32x4 ad[kBlk], acc[kBlk];
+#pragma unroll
+          for (int j = 0; j < kBlk; ++j) {
+            ad[j] = *(const f32x4*)(addt + (4 * kBlk * I + 4 * j + w.g) * astep);
+            acc[j] = zero4;
+          }
+          slab_mfma<2, 16, MAXB>(sl, 16, w, cur, acc);
+          NPF_STAMP(1)
+          if (!grp_b) __syncthreads();
+          NPF_STAMP(2)
+          slot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+#pragma unroll
+          for (int j = 0; j < kBlk; ++j) {
+            f32x4 v;
+            if (mask) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = ad[j][e] > 0.f ? acc[j][e] : 0.f;
+            } else if (relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[j][e] + ad[j][e], 0.f);
+            } else {
+              v = acc[j] + ad[j];
+            }
+            out[kBlk * I + j] = v;
+          }
+          NPF_STAMP(3)
+        }
+#pragma unroll
+        for (int b = 0; b < kMaxB16; ++b) cur[b] = out[b];
+      } else {
+      // Generic path: runtime slab loop with *static* register indices: finished blocks enter a register
       // queue (out[] shifts down by one slab per iteration), so the loop body exists once
       // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
       // cache) and no dynamically indexed register array is needed.
-      NPF_STAMP(5)  // everything between LINEAR slab loops (other ops, layer setup)
       for (int nb = 0; nb < NB; ++nb) {
+        if (!grp_b) NPF_STAMP(4)  // (group A) loop back-edge
         // 1. start filling the other slot with the next slab (possibly the next layer's)
         if (pf.op < g.n_ops) {
-          SlabDma d = dma_begin(pfs, pf.nb, w, smem + (slot ^ 1) * kSlabFloats, !(g.reserved[0] & 1));
+          const int nslot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+          SlabDma d = dma_begin(pfs, pf.nb, w, smem + nslot * kSlabFloats, !(g.reserved[0] & 1));
           NPF_STAMP(6)  // loop top
           dma_finish(pfs, d, w);
           NPF_STAMP(0)  // DMA pieces
@@ -480,14 +596,19 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) acc[j] = zero4;
         const float* sl = smem + slot * kSlabFloats;
+        if (grp_b) {
+          NPF_STAMP(6)
+          __syncthreads();  // group B's barrier: the slab landed (A passed its vmcnt(0))
+          NPF_STAMP(4)      // (group B) barrier wait
+        }
         if (!(g.reserved[0] & 8)) {
           if (N - nb * kSlabRows > 16) slab_mfma_any<2, MAXB>(sl, KB16, w, cur, acc);
           else slab_mfma_any<1, MAXB>(sl, KB16, w, cur, acc);
         }
         NPF_STAMP(1)  // addend loads + MFMA loop
-        if (!(g.reserved[0] & 4)) __syncthreads();  // slab consumed by all waves; vmcnt(0) lands the next one
+        if (!grp_b && !(g.reserved[0] & 4)) __syncthreads();  // slab consumed; vmcnt(0) lands the next one
         NPF_STAMP(2)  // barrier (+ wait for the DMA)
-        slot ^= 1;
+        slot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
 #pragma unroll
         for (int b = 0; b < kMaxB16 - kBlk; ++b) out[b] = out[b + kBlk];
 #pragma unroll
@@ -515,6 +636,7 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
 #pragma unroll
           for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv];
         }
+      }  // generic slab loop
     } else if (opc == NPF_OP_LOAD_PT || opc == NPF_OP_ADD_PT || opc == NPF_OP_MASK_POS || opc == NPF_OP_ROWDOT_PT ||
                opc == NPF_OP_SOFTMAX_BWD) {
       const int FB = o.i0 >> 4;
@@ -633,14 +755,14 @@ __global__ __launch_bounds__(kThreads, MAXB <= 16 ? 2 : 1) void chain_kernel(con
   }
 #ifdef NPF_STAMPS
   NPF_STAMP(5)
-  if (blockIdx.x == 0 && w.tid == 0)
-    for (int i = 0; i < 8; ++i) g_stamps[i] = st_sum[i];
+  if (blockIdx.x == 0 && (w.tid == 0 || w.tid == 256))
+    for (int i = 0; i < 8; ++i) g_stamps[(w.tid >> 5) + i] = st_sum[i];
 #endif
 }
 
 #ifdef NPF_STAMPS
-extern "C" int npf_debug_stamps(unsigned long long* out8) {
-  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
+extern "C" int npf_debug_stamps(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -709,12 +831,10 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
     }
   npf_program_t g = *prog;
   g.n_ops = n_ops;
-  long grid;
-  if (g.wg_per_task)
-    grid = (long)g.n_tasks * ((g.tiles_per_task + npf::kTilesPerWG - 1) / npf::kTilesPerWG);
-  else
-    grid = ((long)g.n_tasks * g.tiles_per_task + npf::kTilesPerWG - 1) / npf::kTilesPerWG;
-  if (grid <= 0 || grid > 0x7fffffffL) return NPF_EINVAL;
+  auto grid_for = [&](int tiles_per_wg) -> long {
+    if (g.wg_per_task) return (long)g.n_tasks * ((g.tiles_per_task + tiles_per_wg - 1) / tiles_per_wg);
+    return ((long)g.n_tasks * g.tiles_per_task + tiles_per_wg - 1) / tiles_per_wg;
+  };
   bool wide = false;
   for (int i = 0; i < g.n_ops; ++i) {
     const npf_op_t& o = g.ops[i];
@@ -724,10 +844,18 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
     if (o.op == NPF_OP_LINEAR && (o.i0 > 256 || o.i1 > 256)) wide = true;
     if (feat_op && o.i0 > 256) wide = true;
   }
+  // 64-point workgroups (two per CU) are the default; the 128-point paired variant is kept as a
+  // tested option (reserved[1] == 2, NPF_FORCE_WG=2): it halves the slab traffic per point but
+  // its lock-step phases overlap slightly worse on MI355X (23.5 vs 23.9 M points/s on config 2).
+  const bool paired = !wide && g.reserved[1] == 2;
+  const long grid = grid_for(paired ? 4 : 2);
+  if (grid <= 0 || grid > 0x7fffffffL) return NPF_EINVAL;
   if (wide)
-    hipLaunchKernelGGL(npf::chain_kernel<32>, dim3((unsigned)grid), dim3(npf::kThreads), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<32, 4>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
+  else if (paired)
+    hipLaunchKernelGGL((npf::chain_kernel<16, 8>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, g);
   else
-    hipLaunchKernelGGL(npf::chain_kernel<16>, dim3((unsigned)grid), dim3(npf::kThreads), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

@@ -104,6 +104,14 @@ if __name__ == "__main__":
     if "occ" in which:
         for nt in (8, 16, 32, 64, 128):
             chain_case(f"occupancy probe: {nt * 1024 // 64} WGs, 8 x linear 256->256", nt, 1024, [(256, 256)] * 8)
+    if "wg" in which:
+        for mode, name in [(1, "64-pt WGs"), (2, "128-pt paired WGs")]:
+            CH.FORCE_WG = mode
+            chain_case(f"[{name}] 8 x linear 256->256", B, T, [(256, 256)] * 8)
+            chain_case(f"[{name}] 8 x linear 128->128", B, T, [(128, 128)] * 8)
+            chain_case(f"[{name}] 8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+            attn_case(f"[{name}] attention fwd B256 C256 T1024 r256", B, C, T, 256)
+        CH.FORCE_WG = 0
     if "ablate" in which:
         for bits, name in [(0, "full"), (1, "no slab DMA"), (2, "no bias loads"), (4, "no barrier"), (8, "no MFMA"),
                            (9, "no MFMA, no DMA"), (15, "nothing"), (16, "no start skew")]:

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 from npf_gwwaveform_amd import _build, _lib  # noqa: E402
 
 so = "/tmp/libnpf_stamps.so"
-cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNPF_STAMPS",
+cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNPF_STAMPS", *sys.argv[1:],
        "-I", os.path.join(ROOT, "include"), "-I", _build.CSRC, *_build.sources(), "-o", so]
 subprocess.run(cmd, check=True)
 _build.LIB_PATH = so
@@ -36,15 +36,19 @@ for n_tasks in (16, 256):
     for W, b in zip(Ws, bs):
         prog.linear(W, 256, 256, bias=b, relu=True)
     prog.store_pt(out, 256)
+    buf0 = (C.c_ulonglong * 16)()
     for _ in range(3):
         prog._launch()
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 16)()
     assert lib.npf_debug_stamps(buf) == 0
-    v = list(buf)
-    tot = sum(v)
-    names = ["dma pieces", "addend+mfma loop", "barrier+dma wait", "epilogue", "-", "between slab loops", "loop top", "cursor advance"]
-    print(f"grid {n_tasks * pts // 64} WGs: total {tot} cycles, per slab iteration (64 slabs):")
-    for n, c in zip(names, v):
-        if c:
-            print(f"   {n:22s} {c / 64:9.1f} cycles/slab  {100.0 * c / tot:5.1f}%")
+    names = ["dma pieces", "addend+mfma loop", "barrier+dma wait", "epilogue", "barrier wait (group B)", "between slab loops",
+             "loop top", "cursor advance"]
+    for grp, v in (("wave 0", list(buf)[:8]), ("wave 4 (group B of a 128-point workgroup)", list(buf)[8:])):
+        tot = sum(v)
+        if not tot:
+            continue
+        print(f"{n_tasks * pts} points, {grp}: total {tot} cycles, per slab iteration (64 slabs):")
+        for n, c in zip(names, v):
+            if c:
+                print(f"   {n:22s} {c / 64:9.1f} cycles/slab  {100.0 * c / tot:5.1f}%")
