@@ -379,6 +379,112 @@ __device__ __forceinline__ void slab_mfma_any(const float* slot, int KB16, const
   }
 }
 
+// The 256-feature slab loop of the fast path: the pinned fragment pipeline of slab_mfma<2, 16>
+// accumulating straight into the slab's two output blocks, plus `side(kb)` after the MFMAs of
+// every 16-feature block.  A wave's own VMEM / VALU instructions issue in the shadow of its own
+// MFMAs for free (the matrix pipe is busy for 32 cycles per MFMA, an issue takes 4-16), while
+// the same instructions issued by the *other* wave of the SIMD during this loop get one issue
+// slot per MFMA (~25 cycles per VALU/LDS instruction, ~85 per VMEM instruction;
+// tools/issue_probe.hip).  So the slab DMA, the addend loads and the previous slab's epilogue
+// all ride inside this loop.
+template <int MAXB, class Side>
+__device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w, const f32x4 (&cur)[MAXB], f32x4& acc0,
+                                               f32x4& acc1, Side side) {
+  constexpr int Kp = 256;
+  const int ps = w.p & 15;
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(slot + w.p * Kp);
+  unsigned addr[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) addr[t] = lds0 + (((t ^ (ps >> 2)) << 6) | ((w.g ^ (ps & 3)) << 4));
+  constexpr int kRowBlk = 16 * Kp * 4;
+  f32x4 fr[2][2] = {};
+  asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:%3"
+               : "=&v"(fr[0][0]), "=&v"(fr[0][1])
+               : "v"(addr[0]), "n"(kRowBlk));
+#define NPF_STEP2(curf, nxtf, kbn)                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6" \
+               : "=&v"(nxtf[0]), "=&v"(nxtf[1]), "+v"(curf[0]), "+v"(curf[1])                            \
+               : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256), "n"(((kbn) >> 2) * 256 + kRowBlk));
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {
+    if (kb + 1 < 16) {
+      if ((kb & 1) == 0) { NPF_STEP2(fr[0], fr[1], kb + 1) } else { NPF_STEP2(fr[1], fr[0], kb + 1) }
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[1][0]), "+v"(fr[1][1]));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][0][s], cur[kb][s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][1][s], cur[kb][s], acc1, 0, 0, 0);
+    }
+    side(kb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef NPF_STEP2
+}
+
+// One 256 -> 256 layer on the fast path, software-pipelined over its 8 slabs.  Stage I:
+//   MFMA loop of slab I accumulating into out[2I], out[2I+1] (initialised with the biases), with
+//   inside it   blocks 0-3 : epilogue of slab I-1, in place (addend / relu / relu-backward mask)
+//               block  4   : addend loads of slab I (HBM; consumed in stage I+1)
+//               blocks 5-12: the 8 DMA pieces of slab I+1 (one SALU add + one instruction each)
+//               block 13   : the bias piece of slab I+1
+//   barrier (slab I consumed by the workgroup, slab I+1 landed).
+// EPI: 0 = out + addend, 1 = relu(out + addend), 2 = addend > 0 ? out : 0.
+template <int EPI, int MAXB, bool PAIRED, class NextLayer>
+__device__ __forceinline__ void fast_layer_256(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
+                                               f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
+                                               const float* addt, int astep, NextLayer next_layer) {
+  constexpr int kSlabFloats = slab_floats(MAXB);
+  f32x4 ad[2] = {};
+  auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
+    const int j = part >> 1, e0 = (part & 1) * 2;
+    f32x4 o = out[2 * I + j];
+#pragma unroll
+    for (int e = e0; e < e0 + 2; ++e) {
+      if (EPI == 2) o[e] = ad[j][e] > 0.f ? o[e] : 0.f;
+      else if (EPI == 1) o[e] = fmaxf(o[e] + ad[j][e], 0.f);
+      else o[e] = o[e] + ad[j][e];
+    }
+    out[2 * I + j] = o;
+  };
+  const char* wbase = (const char*)op.W;
+#pragma unroll
+  for (int I = 0; I < 8; ++I) {
+    const int nxt = PAIRED ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+    float* nslot = smem + nxt * kSlabFloats;
+    const float* sl = smem + slot * kSlabFloats;
+    if (I == 7 && issuer) next_layer(nslot);  // slab 0 of the next LINEAR (generic DMA): `op` changes here
+    if (PAIRED && grp_b) __syncthreads();
+    const float* bias = sl + kSlabRows * 256 + 4 * w.g;
+    out[2 * I] = *(const f32x4*)bias;
+    out[2 * I + 1] = *(const f32x4*)(bias + 16);
+    const char* src = wbase + (size_t)(I + 1) * op.slab_stride * 4;
+    const char* bsrc = op.bias != nullptr ? (const char*)(op.bias + (I + 1) * kSlabRows) : (const char*)g_zero128;
+    slab_mfma_side<MAXB>(sl, w, cur, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+      if (I > 0 && kb < 4) epi_part(I - 1, kb);
+      if (kb == 4) {  // (HBM latency: these must be long gone before the barrier drains vmcnt)
+        ad[0] = *(const f32x4*)(addt + (8 * I + w.g) * astep);
+        ad[1] = *(const f32x4*)(addt + (8 * I + 4 + w.g) * astep);
+      }
+      if (I < 7 && (!PAIRED || issuer)) {
+        if (kb >= 5 && kb < 13) {
+          const int i = kb - 5;
+          dma16_so(src + (size_t)(i * op.step) * 4, op.lo[i], nslot + w.wave * 256 + i * (kWaves * 256));
+        }
+        // (every issuing wave writes the same 32 biases: no wave-dependent branch in this loop)
+        if (kb == 13) dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, nslot + kSlabRows * 256);
+      }
+    });
+    if (!PAIRED || !grp_b) __syncthreads();
+    slot = nxt;
+  }
+#pragma unroll
+  for (int part = 0; part < 4; ++part) epi_part(7, part);
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) cur[b] = out[b];
+}
+
 // reductions over the 4 lane groups that share a point
 __device__ __forceinline__ float xg_sum(float v) {
   v += __shfl_xor(v, 16);
@@ -517,59 +623,22 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       if constexpr (MAXB == 16)
         fast_layer = KB16 == 16 && N == 256 && g.reserved[0] == 0 && (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast));
       if (fast_layer) {
-#pragma unroll
-        for (int I = 0; I < 8; ++I) {
-          if (issuer) {
-            float* nslot = smem + (kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1)) * kSlabFloats;
-            if (I < 7) {
-              dma_fast_slab<8>(pfs, I + 1, nslot, w);
-              dma_fast_bias(pfs, (I + 1) * kSlabRows, nslot, w);
-              if (I == 6) {
-                pf.nb = 7;
-                advance();  // on to the next LINEAR's constants
-              }
-            } else if (pf.op < g.n_ops) {
+        if constexpr (MAXB == 16) {
+          // this layer's slabs 1..7 stream inside the pipeline; then the cursor jumps to the next
+          // LINEAR and its slab 0 goes out through the generic DMA code before the last stage
+          auto next_layer = [&](float* nslot) __attribute__((always_inline)) {
+            pf.nb = 7;
+            advance();
+            if (pf.op < g.n_ops) {
               SlabDma d = dma_begin(pfs, pf.nb, w, nslot, true);
               dma_finish(pfs, d, w);
               advance();
             }
-            NPF_STAMP(0)
-          }
-          const float* sl = smem + slot * kSlabFloats;
-          if (grp_b) {
-            NPF_STAMP(6)
-            __syncthreads();
-            NPF_STAMP(4)
-          }
-          f32x4 ad[kBlk], acc[kBlk];
-#pragma unroll
-          for (int j = 0; j < kBlk; ++j) {
-            ad[j] = *(const f32x4*)(addt + (4 * kBlk * I + 4 * j + w.g) * astep);
-            acc[j] = zero4;
-          }
-          slab_mfma<2, 16, MAXB>(sl, 16, w, cur, acc);
-          NPF_STAMP(1)
-          if (!grp_b) __syncthreads();
-          NPF_STAMP(2)
-          slot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
-#pragma unroll
-          for (int j = 0; j < kBlk; ++j) {
-            f32x4 v;
-            if (mask) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = ad[j][e] > 0.f ? acc[j][e] : 0.f;
-            } else if (relu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[j][e] + ad[j][e], 0.f);
-            } else {
-              v = acc[j] + ad[j];
-            }
-            out[kBlk * I + j] = v;
-          }
-          NPF_STAMP(3)
+          };
+          if (mask) fast_layer_256<2, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else if (relu) fast_layer_256<1, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else fast_layer_256<0, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
         }
-#pragma unroll
-        for (int b = 0; b < kMaxB16; ++b) cur[b] = out[b];
       } else {
       // Generic path: runtime slab loop with *static* register indices: finished blocks enter a register
       // queue (out[] shifts down by one slab per iteration), so the loop body exists once
