@@ -90,20 +90,142 @@ def cpu_baseline(kind: str, r: int, L: int, C: int, T: int, budget_s: float = 12
                       f"(C={C}, T={T}, r={r}, L={L}), {el:.1f} s, torch {torch.__version__} CPU, {cores} threads"}
 
 
+FLOP_PER_PT_DECODE_R512_L4 = 3_149_824  # (L+2) 2 r^2 + 4 r dy at r = 512, L = 4, dy = 2
+
+
+def decode_model(r: int, L: int, device):
+    import npf_gwwaveform_amd as A
+
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = A.CNP(1, 2, r_dim=r, Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, hidden_size=r), is_sum_merge=True))
+    return m.to(device).eval()
+
+
+def cpu_baseline_decode(r: int, L: int, T: int, budget_s: float = 12.0):
+    """The oracle's decode(X_trgt_enc, R_trgt) (base.py:327-367 restated) on the host cores, batch 2."""
+    from oracle import npf_oracle as O
+
+    avail = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = max(1, min(avail, int(os.environ.get("NPF_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    B = 2
+    cfg = O.OracleConfig(kind="CNP", x_dim=1, y_dim=2, r_dim=r)
+    params = O.init_params(cfg, 0, 2, L)
+    g = torch.Generator().manual_seed(5)
+    Xt, R = torch.randn(B, T, r, generator=g) * 0.5, torch.randn(1, B, T, r, generator=g) * 0.5
+    with torch.no_grad():
+        O.decode(cfg, params, Xt, R)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.decode(cfg, params, Xt, R)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 200:
+                break
+    return {"value": B * T * n / el, "unit": "target-points/s", "cores": cores, "kind": "port",
+            "sample": f"{n} decode passes of the CPU oracle with batch {B} (T={T}, r={r}, L={L}), {el:.1f} s, "
+                      f"torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main_decode(args, rank, world, dev):
+    """BASELINE config 5 per GPU: decode(X_trgt_enc, R_trgt) only, 512-wide 4-layer decoder, 4096
+    target points per waveform, 4096 / 8 = 512 waveforms per GPU, encoder outputs resident in HBM."""
+    from npf_gwwaveform_amd import chain as CH
+
+    r, L, T = args.r, args.layers, args.trgt
+    B = args.batch
+    model = decode_model(r, L, dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    Xt = torch.randn(B, T, r, device=dev, generator=g) * 0.5
+    R = torch.randn(1, B, T, r, device=dev, generator=g) * 0.5
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            p = model.decode(Xt, R)
+        return p.base_dist.loc
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loc = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * T * args.steps / elapsed
+    roofline, kernels = None, {}
+    if rank == 0 and not args.no_roofline:
+        CH.PROFILE = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in CH.PROFILE:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        CH.PROFILE = None
+        for name, (n, fl, sec) in agg.items():
+            kernels[name] = {"launches_per_step": n / 2, "avg_launch_ms": sec / n * 1e3,
+                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12}
+        name, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+        ach = fl / sec * 1e-12
+        roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_decode(r, L, T)
+    if rank == 0:
+        flop_pt = FLOP_PER_PT_DECODE_R512_L4 if (r, L) == (512, 4) else None
+        print(json.dumps({
+            "metric": "waveform target-points/sec (decode only)", "value": value, "unit": "target-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: decode(X_trgt_enc, R_trgt) only, {r}-wide {L}-layer decoder, {T} target "
+                                   f"points per waveform, {B} waveforms per GPU, fp32, encoder outputs resident in HBM "
+                                   f"(row-major [B,T,r] as the reference's decode takes them)",
+                       "tasks_per_gpu": B, "global_tasks": B * world, "target_points": T, "r_dim": r,
+                       "parallelism": f"replicas x{world} (no collective)", "checksum_loc": float(loc.double().sum().item()),
+                       "decode_tflops_algorithmic": (value * flop_pt * 1e-12) if flop_pt else None, "kernels": kernels},
+            "roofline": roofline, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="train", choices=["train", "decode"],
+                    help="train = BASELINE config 2 (the headline metric); decode = config 5 (decode-only, r=512, T=4096)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="attncnp", choices=["attncnp", "attnlnp"])
-    ap.add_argument("--batch", type=int, default=256, help="tasks per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="tasks per GPU (train: 256, decode: 512)")
     ap.add_argument("--ctx", type=int, default=256)
-    ap.add_argument("--trgt", type=int, default=1024)
-    ap.add_argument("--r", type=int, default=256)
+    ap.add_argument("--trgt", type=int, default=None, help="target points per task (train: 1024, decode: 4096)")
+    ap.add_argument("--r", type=int, default=None, help="feature width (train: 256, decode: 512)")
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    dflt = {"train": (256, 1024, 256), "decode": (512, 4096, 512)}[args.workload]
+    args.batch = dflt[0] if args.batch is None else args.batch
+    args.trgt = dflt[1] if args.trgt is None else args.trgt
+    args.r = dflt[2] if args.r is None else args.r
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +239,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "decode":
+        main_decode(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from npf_gwwaveform_amd import chain as CH
     from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
