@@ -234,11 +234,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal on a one-GPU box (not a measurement): NPF_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and exchanges gradients over gloo, to exercise the N > 1 control flow end to end
+    rehearsal = os.environ.get("NPF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "decode":
         main_decode(args, rank, world, dev)
@@ -277,13 +285,16 @@ def main():
 
     roofline = None
     kernels = {}
-    if rank == 0 and not args.no_roofline:
-        # instrumented pass: HIP events around every kernel launch on the launch stream
-        CH.PROFILE = []
-        n_prof = 3
+    n_prof = 3
+    if not args.no_roofline:
+        # instrumented pass: HIP events around every kernel launch on the launch stream (rank 0);
+        # every rank runs these steps because a step contains the gradient all-reduce
+        if rank == 0:
+            CH.PROFILE = []
         for i in range(n_prof):
             trainer.step(batches[i % len(batches)])
-        torch.cuda.synchronize()
+        sync()
+    if rank == 0 and not args.no_roofline:
         agg = {}
         if os.environ.get("NPF_BENCH_VERBOSE"):
             per = len(CH.PROFILE) // n_prof
@@ -318,8 +329,6 @@ def main():
                     break
             except Exception:
                 pass
-    elif world > 1 and not args.no_roofline:
-        pass
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -339,7 +348,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
                 "workload": f"BASELINE config 2: {'AttnCNP' if args.model == 'attncnp' else 'AttnLNP(is_q_zCct, n_z=1)'} "
                             f"scaledot, r={args.r}, {args.layers}-layer xy-encoder/decoder, {C} context / {T} target "
