@@ -423,6 +423,7 @@ class _ChainFn(torch.autograd.Function):
         ctx.train = train
         if non_diff:
             ctx.mark_non_differentiable(*non_diff)
+        ctx.set_materialize_grads(False)  # outputs without a gradient arrive as None, not as zero-filled tensors
         return tuple(outputs)
 
     @staticmethod

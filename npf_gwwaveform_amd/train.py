@@ -48,7 +48,8 @@ class Trainer:
         self.model, self.criterion = model, criterion
         self.flat = FlatParameters(model.parameters())
         self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
-        self.opt = torch.optim.Adam([self.flat.flat], lr=lr)
+        # one fused kernel per step on the flat buffer (the default implementation is ~8 launches)
+        self.opt = torch.optim.Adam([self.flat.flat], lr=lr, fused=self.flat.flat.is_cuda)
         self.model.train()
         self.criterion.train()
 

@@ -176,3 +176,22 @@ def test_training_wider_than_256_is_refused_loudly():
     ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, m.to_hidden.weight, m.to_hidden.bias)),
                                      m.out.weight, m.out.bias)
     assert_close(y, ref, what="512-wide MLP inference")
+
+
+def test_training_inputs_outside_unit_range_raise_like_the_reference():
+    """base.py:241-247: X outside [-1, 1] (or NaN) raises ValueError in training mode only."""
+    case = specs.CASES["g1_cnp_c1"]
+    model = build_model(case, DEV).train()
+    inp = {k: v.to(DEV) for k, v in specs.make_inputs(case).items()}
+    model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+    bad = inp["X_trgt"].clone()
+    bad[0, 0, 0] = 1.5
+    with pytest.raises(ValueError, match=r"\[-1,1\]"):
+        model(inp["X_cntxt"], inp["Y_cntxt"], bad, inp["Y_trgt"])
+    nan = inp["X_cntxt"].clone()
+    nan[1, 2, 0] = float("nan")
+    with pytest.raises(ValueError):
+        model(nan, inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+    model.eval()
+    with torch.no_grad():
+        model(inp["X_cntxt"], inp["Y_cntxt"], bad, inp["Y_trgt"])  # no check outside training
