@@ -73,7 +73,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # NPF_HIP_LIB: development override to A/B two builds of the same ABI on one box
+    return os.environ.get("NPF_HIP_LIB") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:

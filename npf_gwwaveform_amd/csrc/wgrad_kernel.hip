@@ -86,12 +86,19 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 
   // DMA: piece q of an operand = its quad rows 2q, 2q+1; wave w issues pieces w, w+16, ...: the
   // swizzle term (row & 15) = (2w + (lane >> 5)) & 15 is the same for all of them
-  const int dma_lane = (lane >> 5) * 128 + (((lane & 31) ^ ((2 * wave + (lane >> 5)) & 15)) << 2);
+  // (uniform 64-bit base + 32-bit lane offset = the SGPR-base form of the DMA instruction: no VALU
+  // address arithmetic per piece; the operand pointers are pinned in SGPRs for the whole loop)
+  const unsigned dma_lane = 4u * (unsigned)((lane >> 5) * 128 + (((lane & 31) ^ ((2 * wave + (lane >> 5)) & 15)) << 2));
+  const char* dz_base = (const char*)job.dZ;
+  const char* a_base = (const char*)job.A;
+  asm volatile("" : "+s"(dz_base), "+s"(a_base));
   auto tile_dma = [&](long t, float* buf) {
-    const float* zsrc = job.dZ + (size_t)t * Np * 32 + dma_lane;
-    const float* asrc = job.A + (size_t)t * Kp * 32 + dma_lane;
-    for (int q = wave; q < (Np >> 3); q += kWgWaves) wg_dma16(zsrc + q * 256, buf + q * 256);
-    for (int q = wave; q < (Kp >> 3); q += kWgWaves) wg_dma16(asrc + q * 256, buf + kOp + q * 256);
+    const char* zsrc = dz_base + (size_t)t * Np * 128;
+    const char* asrc = a_base + (size_t)t * Kp * 128;
+    for (int q = wave; q < (Np >> 3); q += kWgWaves)
+      wg_dma16((const float*)(zsrc + (size_t)q * 1024 + (size_t)dma_lane), buf + q * 256);
+    for (int q = wave; q < (Kp >> 3); q += kWgWaves)
+      wg_dma16((const float*)(asrc + (size_t)q * 1024 + (size_t)dma_lane), buf + kOp + q * 256);
   };
 
   __syncthreads();
