@@ -1,0 +1,74 @@
+"""GPU parity sweep over shapes the golden vectors do not cover: the HIP models against the CPU
+oracle (oracle/npf_oracle.py, itself pinned bit-exactly to the reference by tests/test_oracle.py)
+on the same seeded weights and inputs.  Feature widths that are not multiples of 32 or of 4,
+wider x / y, ragged context / target counts, several latent samples, homoskedastic heads.
+Tolerances as in tests/test_hip_models.py (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+import specs
+from helpers import EpsIndependent, assert_close, build_loss, build_model
+from oracle import npf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOSSES = {"cnpf": O.cnpf_loss, "elbo": O.elbo_loss, "nll": O.nll_loss}
+
+SWEEP = {
+    "cnp_r48": dict(kind="CNP", r=48, L_xy=2, L_dec=3, dx=1, dy=2, B=5, C=17, T=45),
+    "cnp_r100_dx3_dy1": dict(kind="CNP", r=100, L_xy=1, L_dec=2, dx=3, dy=1, B=3, C=33, T=65),
+    "cnp_r200_L1": dict(kind="CNP", r=200, L_xy=1, L_dec=1, dx=2, dy=2, B=2, C=70, T=130),
+    "cnp_r36_homosk": dict(kind="CNP", r=36, L_xy=2, L_dec=2, dx=1, dy=4, B=4, C=12, T=31, is_heteroskedastic=False),
+    "lnp_latent_nz3_r40": dict(kind="LNP", r=40, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=50, encoded_path="latent",
+                               is_q_zCct=True, n_z=3),
+    "lnp_both_nz2_r72": dict(kind="LNP", r=72, L_xy=2, L_dec=2, dx=2, dy=3, B=2, C=31, T=33, encoded_path="both",
+                             is_q_zCct=False, n_z=2),
+    "attncnp_r96": dict(kind="AttnCNP", r=96, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=37, T=70),
+    "attncnp_r160_c255": dict(kind="AttnCNP", r=160, L_xy=2, L_dec=2, dx=2, dy=2, B=2, C=255, T=129),
+    "attncnp_r256_c256_t100": dict(kind="AttnCNP", r=256, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=256, T=100),
+    "attncnp_r44": dict(kind="AttnCNP", r=44, L_xy=2, L_dec=2, dx=1, dy=1, B=2, C=3, T=9),
+    "attnlnp_nz3_r64": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=40, T=48, is_q_zCct=True, n_z=3),
+    "attnlnp_nz2_r104_noq": dict(kind="AttnLNP", r=104, L_xy=1, L_dec=2, dx=1, dy=2, B=2, C=19, T=35, is_q_zCct=False,
+                                 n_z=2),
+}
+
+
+def _oracle(case, inp, params):
+    cfg = specs.cfg_of(case)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = O.forward(cfg, p, inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"], eps=inp.get("eps"),
+                    n_z=case.get("n_z", 1), training=True)
+    loss = LOSSES[specs.loss_name(case)](out, inp["Y_trgt"])
+    loss.backward()
+    return p, out, loss
+
+
+@pytest.mark.parametrize("name", list(SWEEP))
+def test_hip_matches_oracle_on_odd_shapes(name):
+    case = SWEEP[name]
+    params = specs.make_params(case, seed=11)
+    inp = specs.make_inputs(case, seed=4321)
+    ref_p, ref_out, ref_loss = _oracle(case, inp, params)
+
+    model = build_model(case, DEV, params=params)
+    dinp = {k: v.to(DEV) for k, v in inp.items()}
+    if "eps" in dinp:
+        EpsIndependent.eps = dinp["eps"]
+    crit = build_loss(case)
+    model.train()
+    crit.train()
+    out = model(dinp["X_cntxt"], dinp["Y_cntxt"], dinp["X_trgt"], dinp["Y_trgt"])
+    loss = crit(out, dinp["Y_trgt"])
+    loss.backward()
+
+    assert_close(out[0].base_dist.loc, ref_out["loc"], what="loc")
+    assert_close(out[0].base_dist.scale, ref_out["scale"], what="scale")
+    np.testing.assert_allclose(out[0].base_dist.scale.detach().cpu().numpy(), ref_out["scale"].detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=2e-5)
+    if out[1] is not None:
+        assert_close(out[1], ref_out["z_samples"], what="z_samples")
+    for k, p in model.named_parameters():
+        ref = ref_p[k].grad if ref_p[k].grad is not None else torch.zeros_like(ref_p[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(got, ref, tol=1e-4, what=f"grad {k}")
