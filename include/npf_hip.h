@@ -58,7 +58,10 @@ enum npf_opcode {
   NPF_OP_LOAD_ROWS = 3,    /* cur <- row-major p0 [task][pt][i0], i0 <= 32, zero padded        */
   NPF_OP_STORE_ROWS = 4,   /* row-major p0 [task][pt][i0] <- cur features < i0                 */
   NPF_OP_LINEAR = 5,       /* cur <- act(W cur + b [+ PT addend p2]); see npf_op_t fields       */
-  NPF_OP_SOFTMAX = 6,      /* cur <- softmax over features < i0 of f0*cur                       */
+  NPF_OP_SOFTMAX = 6,      /* cur <- softmax over features < i0 of f0*cur.  i1 = 1: also store the
+                              row statistics (max of cur, sum of exp(f0*(cur-max))) to
+                              p0[task][pt][2]; i1 = 2: use the statistics stored in p0 instead
+                              of the row's own (one block of a softmax over > 512 keys)          */
   NPF_OP_ADD_PT = 7,       /* cur <- cur + PT32 tensor p0 (i0 = F), optional relu (i1)          */
   NPF_OP_MASK_POS = 8,     /* cur <- (PT32 p0 > 0) ? cur : 0 (i0 = F)      [relu backward]      */
   NPF_OP_ADD_TASKVEC = 9,  /* cur <- cur + p0[task][i0 features] (row-major), optional relu (i1)*/

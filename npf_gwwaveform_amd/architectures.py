@@ -203,6 +203,18 @@ class DotAttender(nn.Module):
         return (ch.attn_scores(keys_pt, n_keys, keys_tr=keys_tr).softmax(scale)
                 .attn_values(values_pt, self.value_size, values_tr=values_tr))
 
+    def fits_fused(self, n_keys: int) -> bool:
+        """Can ``append_to`` keep a whole score row in registers (else: ``attend_pt``)."""
+        return n_keys <= NPF_MAX_TRAIN_FEATURES
+
+    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
+        """PT32 in, PT32 out, any number of keys (blocked softmax, attention_long.py)."""
+        from .attention_long import long_scaledot_attention
+
+        scale = 1.0 / math.sqrt(self.kq_size) if self.is_scale else 1.0
+        return long_scaledot_attention(queries_pt, keys_pt, values_pt, n_keys, n_queries, self.value_size, scale,
+                                       k_tr=keys_tr, v_tr=values_tr)
+
     def forward(self, keys, queries, values):
         B, C, d = keys.shape
         T = queries.shape[1]
@@ -210,6 +222,9 @@ class DotAttender(nn.Module):
             raise NotImplementedError("relative-position (4-D) keys are not on the hot path")
         if C == 0:
             raise ValueError("attention over zero keys")
+        if not self.fits_fused(C):
+            o = self.attend_pt(FN.pack_pt(queries), FN.pack_pt(keys), FN.pack_pt(values), C, T)
+            return FN.unpack_pt(o, T, self.out_size)
         ch = Chain(B, T, keys.device, wg_per_task=True)
         ch.input_pt(FN.pack_pt(queries), d)
         self.append_to(ch, FN.pack_pt(keys), FN.pack_pt(values), C).output_pt()

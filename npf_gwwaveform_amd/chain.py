@@ -107,8 +107,9 @@ class Program:
     def store_rows(self, t, nd):
         self._op(op=L.OP_STORE_ROWS, i0=nd, p0=self._p(t))
 
-    def softmax(self, n_valid, scale):
-        self._op(op=L.OP_SOFTMAX, i0=n_valid, f0=scale)
+    def softmax(self, n_valid, scale, mode=0, stats=None):
+        """mode 1: also store (row max, row sum) to ``stats`` [n_tasks, pts, 2]; mode 2: take them from it."""
+        self._op(op=L.OP_SOFTMAX, i0=n_valid, i1=mode, f0=scale, p0=self._p(stats))
 
     def add_taskvec(self, t, F, relu=False, modulus=0):
         self._op(op=L.OP_ADD_TASKVEC, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
@@ -270,7 +271,8 @@ class Chain:
             raise ValueError("attention needs wg_per_task=True")
         if n_keys > L.NPF_MAX_TRAIN_FEATURES:
             raise NotImplementedError(
-                f"more than {L.NPF_MAX_TRAIN_FEATURES} context points per task are not supported yet")
+                f"a fused score row holds at most {L.NPF_MAX_TRAIN_FEATURES} context points; longer contexts go "
+                "through DotAttender.attend_pt (attention_long.py)")
         self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F, "tr": keys_tr}))
         self.F = n_keys
         return self

@@ -774,18 +774,31 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
           if (pt_ok && f < nd) dst[f] = cur[b][s];
         }
     } else if (opc == NPF_OP_SOFTMAX) {
-      const int nvalid = o.i0;
+      // i1 = 0: softmax of the row; 1: the same, and (max, sum) go to p0[task][pt][2]; 2: max and
+      // sum come from p0 -- a block of a longer row whose statistics were combined on the way
+      const int nvalid = o.i0, smode = o.i1;
       const int FB = ((nvalid + 31) >> 5) * 2;
       const float scale = o.f0;
-      float m = -INFINITY;
+      float* stats = (float*)o.p0 + ((size_t)w.task * g.pts_per_task + pt) * 2;
+      float m = -INFINITY, sum = 0.f;
+      if (smode == 2) {
+        if (pt_ok) {
+          m = stats[0];
+          sum = stats[1];
+        } else {
+          m = 0.f;
+          sum = 1.f;
+        }
+      } else {
 #pragma unroll
-      for (int b = 0; b < kMaxB16; ++b)
-        if (b < FB)
+        for (int b = 0; b < kMaxB16; ++b)
+          if (b < FB)
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (16 * b + 4 * w.g + s < nvalid) m = fmaxf(m, cur[b][s]);
-      m = xg_max(m);
-      float sum = 0.f;
+            for (int s = 0; s < 4; ++s)
+              if (16 * b + 4 * w.g + s < nvalid) m = fmaxf(m, cur[b][s]);
+        m = xg_max(m);
+      }
+      float part = 0.f;
 #pragma unroll
       for (int b = 0; b < kMaxB16; ++b)
         if (b < FB)
@@ -794,9 +807,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
             const bool ok = 16 * b + 4 * w.g + s < nvalid;
             const float e = ok ? expf((cur[b][s] - m) * scale) : 0.f;
             cur[b][s] = e;
-            sum += e;
+            part += e;
           }
-      sum = xg_sum(sum);
+      if (smode != 2) sum = xg_sum(part);
+      if (smode == 1 && pt_ok && w.g == 0) {
+        stats[0] = m;
+        stats[1] = sum;
+      }
       const float inv = 1.f / sum;
 #pragma unroll
       for (int b = 0; b < kMaxB16; ++b)
@@ -871,7 +888,8 @@ static int validate(const npf_program_t* g) {
         if (o.i0 <= 0 || o.i0 > 32 || !o.p0) return NPF_EINVAL;
         break;
       case NPF_OP_SOFTMAX:
-        if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES) return NPF_EINVAL;
+        if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || o.i1 < 0 || o.i1 > 2) return NPF_EINVAL;
+        if (o.i1 != 0 && (!o.p0 || (((uintptr_t)o.p0) & 7))) return NPF_EINVAL;
         break;
       case NPF_OP_STORE_TR:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || !o.p0 || o.i1 < g->tiles_per_task * 32) return NPF_EINVAL;

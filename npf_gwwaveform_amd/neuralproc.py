@@ -433,14 +433,23 @@ class AttnCNP(NeuralProcessFamily):
             return None
         return self._xyenc_pt(X_enc_pt, Y, B, P)
 
+    def _attend_into(self, ch, Xc_pt, R, Xt_pt, C, T):
+        """cur of ``ch`` <- attention of the targets over the context (attnnp.py:118-131): fused into
+        the chain while a score row fits the registers, blocked (attention_long.py) beyond that."""
+        k_tr, v_tr = getattr(Xc_pt, "_npf_tr", None), getattr(R, "_npf_tr", None)
+        if self.attender.fits_fused(C):
+            ch.input_pt(Xt_pt, self.x_transf_dim)
+            self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr)
+        else:
+            ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T, keys_tr=k_tr, values_tr=v_tr), self.r_dim)
+        return ch
+
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
         ch = Chain(B, T, Xt_pt.device, wg_per_task=True)
         if C == 0:
             ch.input_pt(torch.zeros_like(Xt_pt), self.r_dim)
         else:
-            ch.input_pt(Xt_pt, self.x_transf_dim)
-            self.attender.append_to(ch, Xc_pt, R, C, keys_tr=getattr(Xc_pt, "_npf_tr", None),
-                                        values_tr=getattr(R, "_npf_tr", None))
+            self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
         self.decoder.append_to(ch, x1_pt=Xt_pt).output_rows()
         return ch.run()[0]
 
@@ -501,18 +510,14 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
             if C == 0:
                 ch.input_pt(torch.zeros_like(Xt_pt), r)
             else:
-                ch.input_pt(Xt_pt, self.x_transf_dim)
-                self.attender.append_to(ch, Xc_pt, R, C, keys_tr=getattr(Xc_pt, "_npf_tr", None),
-                                        values_tr=getattr(R, "_npf_tr", None))
+                self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
             mod = 0
         else:
             if C == 0:
                 R_det = torch.zeros_like(Xt_pt)
             else:
                 cha = Chain(B, T, dev, wg_per_task=True)
-                cha.input_pt(Xt_pt, self.x_transf_dim)
-                self.attender.append_to(cha, Xc_pt, R, C, keys_tr=getattr(Xc_pt, "_npf_tr", None),
-                                        values_tr=getattr(R, "_npf_tr", None)).output_pt()
+                self._attend_into(cha, Xc_pt, R, Xt_pt, C, T).output_pt()
                 (R_det,) = cha.run()
             ch = Chain(rows, T, dev, wg_per_task=True)
             ch.input_pt(R_det, r, modulus=B)

@@ -29,6 +29,14 @@ SWEEP = {
     "attncnp_r256_c256_t100": dict(kind="AttnCNP", r=256, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=256, T=100),
     "attncnp_r44": dict(kind="AttnCNP", r=44, L_xy=2, L_dec=2, dx=1, dy=1, B=2, C=3, T=9),
     "attnlnp_nz3_r64": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=40, T=48, is_q_zCct=True, n_z=3),
+    # more context points than one fused score row holds: blocked softmax (attention_long.py)
+    "attncnp_c300_r64": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=300, T=70),
+    "attncnp_c513_r96": dict(kind="AttnCNP", r=96, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=513, T=33),
+    "attncnp_c1030_r256": dict(kind="AttnCNP", r=256, L_xy=1, L_dec=1, dx=1, dy=2, B=1, C=1030, T=64),
+    "attnlnp_c400_nz2_r64": dict(kind="AttnLNP", r=64, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=400, T=40, is_q_zCct=True,
+                                 n_z=2),
+    "attnlnp_c260_nz1_r32": dict(kind="AttnLNP", r=32, L_xy=1, L_dec=1, dx=1, dy=1, B=3, C=260, T=50, is_q_zCct=False,
+                                 n_z=1),
     "attnlnp_nz2_r104_noq": dict(kind="AttnLNP", r=104, L_xy=1, L_dec=2, dx=1, dy=2, B=2, C=19, T=35, is_q_zCct=False,
                                  n_z=2),
 }
@@ -72,3 +80,24 @@ def test_hip_matches_oracle_on_odd_shapes(name):
         ref = ref_p[k].grad if ref_p[k].grad is not None else torch.zeros_like(ref_p[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         assert_close(got, ref, tol=1e-4, what=f"grad {k}")
+
+
+def test_dot_attender_long_context_matches_torch():
+    """DotAttender.forward (attention.py:129-164,204-220) with 1000 keys: forward and all three
+    gradients against a float64 torch evaluation of softmax(Q K^T / sqrt(d)) V."""
+    import npf_gwwaveform_amd as A
+
+    g = torch.Generator().manual_seed(3)
+    B, C, T, d = 2, 1000, 77, 128
+    K, Q, V = (torch.randn(B, n, d, generator=g) * s for n, s in ((C, 1.5), (T, 1.5), (C, 1.0)))
+    dO = torch.randn(B, T, d, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (K, Q, V)]
+    ref = torch.softmax(ref_in[1] @ ref_in[0].transpose(1, 2) / d ** 0.5, dim=-1) @ ref_in[2]
+    ref.backward(dO.double())
+    att = A.get_attender("scaledot", d, d, d)
+    dev_in = [t.to(DEV).requires_grad_(True) for t in (K, Q, V)]
+    out = att(*dev_in)
+    out.backward(dO.to(DEV))
+    assert_close(out, ref, what="context vectors")
+    for name, a, b in zip(("dK", "dQ", "dV"), dev_in, ref_in):
+        assert_close(a.grad, b.grad, tol=2e-5, what=name)
