@@ -195,3 +195,84 @@ def test_training_inputs_outside_unit_range_raise_like_the_reference():
     model.eval()
     with torch.no_grad():
         model(inp["X_cntxt"], inp["Y_cntxt"], bad, inp["Y_trgt"])  # no check outside training
+
+
+def _c2_model_and_batch(B, seed=7):
+    """BASELINE config 2 at full size: AttnCNP r=256 L=4, 256 context / 1024 target points."""
+    from npf_gwwaveform_amd.train import synthetic_waveform_batch
+
+    case = dict(specs.CASES["g3_attncnp_c2"], B=B)
+    model = build_model(case, DEV).train()
+    return model, synthetic_waveform_batch(B, case["C"], case["T"], seed, DEV)
+
+
+def test_full_size_config2_properties():
+    """Size-independent properties at BASELINE config 2's full size (256 tasks x 1024 targets), where
+    the CPU oracle is too slow to be the checker:
+      * tasks are independent (base.py:177-239 has no cross-task op before the loss mean): a task
+        evaluated alone gives the same loc / sigma as inside the full batch;
+      * a target's prediction does not depend on the other targets of its task;
+      * permuting the context points leaves the predictions unchanged (attention sums over them);
+      * the gradient of the batch-mean loss is the mean of the two half-batch gradients."""
+    import npf_gwwaveform_amd as A
+
+    B = 256
+    model, batch = _c2_model_and_batch(B)
+    crit = A.CNPFLoss()
+    p = model(batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"])[0]
+    loc, scale = p.base_dist.loc.detach(), p.base_dist.scale.detach()
+    assert torch.isfinite(loc).all() and torch.isfinite(scale).all() and (scale >= 0.01).all()
+    for i in (0, 101, 255):
+        one = {k: v[i:i + 1] for k, v in batch.items()}
+        pi = model(one["X_cntxt"], one["Y_cntxt"], one["X_trgt"], one["Y_trgt"])[0]
+        assert_close(pi.base_dist.loc, loc[:, i:i + 1], tol=1e-6, what=f"task {i} alone: loc")
+        assert_close(pi.base_dist.scale, scale[:, i:i + 1], tol=1e-6, what=f"task {i} alone: scale")
+    sub = slice(100, 357)
+    ps = model(batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"][:, sub], batch["Y_trgt"][:, sub])[0]
+    assert_close(ps.base_dist.loc, loc[:, :, sub], tol=1e-6, what="target subset: loc")
+    assert_close(ps.base_dist.scale, scale[:, :, sub], tol=1e-6, what="target subset: scale")
+    perm = torch.randperm(batch["X_cntxt"].shape[1], device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    pp = model(batch["X_cntxt"][:, perm], batch["Y_cntxt"][:, perm], batch["X_trgt"], batch["Y_trgt"])[0]
+    assert_close(pp.base_dist.loc, loc, tol=1e-5, what="context permutation: loc")
+    assert_close(pp.base_dist.scale, scale, tol=1e-5, what="context permutation: scale")
+
+    def grads(lo, hi):
+        model.zero_grad(set_to_none=True)
+        b = {k: v[lo:hi] for k, v in batch.items()}
+        out = model(b["X_cntxt"], b["Y_cntxt"], b["X_trgt"], b["Y_trgt"])
+        loss = crit(out, b["Y_trgt"])
+        loss.backward()
+        return loss.item(), {k: q.grad.clone() for k, q in model.named_parameters()}
+
+    l_full, g_full = grads(0, B)
+    l_a, g_a = grads(0, B // 2)
+    l_b, g_b = grads(B // 2, B)
+    np.testing.assert_allclose(l_full, 0.5 * (l_a + l_b), rtol=1e-5)
+    for k in g_full:
+        assert_close(g_full[k], 0.5 * (g_a[k] + g_b[k]), tol=1e-4, what=f"grad linearity {k}")
+
+
+def test_full_size_config5_decode_properties():
+    """BASELINE config 5 per-GPU size (512 waveforms x 4096 targets, r = 512): decoding a subset of the
+    waveforms / targets gives the same loc / sigma as the corresponding part of the full decode."""
+    import warnings
+    from functools import partial
+
+    import npf_gwwaveform_amd as A
+
+    r, L, B, T = 512, 4, 512, 4096
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = A.CNP(1, 2, r_dim=r, Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, hidden_size=r),
+                                                                  is_sum_merge=True)).to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    Xt = torch.randn(B, T, r, device=DEV, generator=g) * 0.5
+    R = torch.randn(1, B, T, r, device=DEV, generator=g) * 0.5
+    with torch.no_grad():
+        p = model.decode(Xt, R)
+        loc, scale = p.base_dist.loc, p.base_dist.scale
+        assert torch.isfinite(loc).all() and (scale >= 0.01).all()
+        ps = model.decode(Xt[7:9, 1000:1100].contiguous(), R[:, 7:9, 1000:1100].contiguous())
+    assert_close(ps.base_dist.loc, loc[:, 7:9, 1000:1100], tol=1e-6, what="decode subset: loc")
+    assert_close(ps.base_dist.scale, scale[:, 7:9, 1000:1100], tol=1e-6, what="decode subset: scale")
