@@ -175,16 +175,18 @@ def main_decode(args, rank, world, dev):
             step()
         torch.cuda.synchronize()
         agg = {}
-        for name, flops, e0, e1 in CH.PROFILE:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, flops, e0, e1, nbytes in CH.PROFILE:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += nbytes
         CH.PROFILE = None
-        for name, (n, fl, sec) in agg.items():
+        for name, (n, fl, sec, nb) in agg.items():
             kernels[name] = {"launches_per_step": n / 2, "avg_launch_ms": sec / n * 1e3,
-                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12}
-        name, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
+                             "algorithmic_hbm_gb_per_launch": nb / n * 1e-9}
+        name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
         ach = fl / sec * 1e-12
         roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
@@ -298,20 +300,23 @@ def main():
         agg = {}
         if os.environ.get("NPF_BENCH_VERBOSE"):
             per = len(CH.PROFILE) // n_prof
-            for name, flops, e0, e1 in CH.PROFILE[-per:]:
+            for name, flops, e0, e1, nbytes in CH.PROFILE[-per:]:
                 ms = e0.elapsed_time(e1)
-                print(f"  {name:14s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s", file=sys.stderr)
-        for name, flops, e0, e1 in CH.PROFILE:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+                print(f"  {name:14s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s "
+                      f"{nbytes * 1e-9:7.3f} GB (algorithmic) {nbytes / ms * 1e-6:7.0f} GB/s", file=sys.stderr)
+        for name, flops, e0, e1, nbytes in CH.PROFILE:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += nbytes
         CH.PROFILE = None
-        for name, (n, fl, sec) in agg.items():
+        for name, (n, fl, sec, nb) in agg.items():
             kernels[name] = {"launches_per_step": n / n_prof, "avg_launch_ms": sec / n * 1e3,
-                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12}
+                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
+                             "algorithmic_hbm_gb_per_launch": nb / n * 1e-9}
         dom = max(agg.items(), key=lambda kv: kv[1][2])
-        name, (n, fl, sec) = dom
+        name, (n, fl, sec, nb) = dom
         ach = fl / sec * 1e-12
         roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_TFLOPS, "traffic": None}

@@ -23,7 +23,7 @@ from . import _lib as L
 
 
 # bench.py sets this to a list to time every launch with HIP events on the launch stream:
-# entries are (kernel, algorithmic flops, start event, end event)
+# entries are (kernel, algorithmic flops, start event, end event, algorithmic HBM bytes)
 PROFILE = None
 DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microbench.py)
 # tests / tools: 1 = 64-point workgroups, 2 = 128-point (paired) workgroups, 0 = the library's choice
@@ -126,6 +126,27 @@ class Program:
         """Algorithmic GEMM FLOPs of one launch: 2*K*N per LINEAR per valid point."""
         return sum(2 * o.i0 * o.i1 for o in self.ops if o.op == L.OP_LINEAR) * self.n_tasks * self.pts
 
+    def hbm_bytes(self) -> int:
+        """Algorithmic HBM bytes of one launch: every per-point tensor the program loads or stores
+        once (padded tiles included), every weight matrix once (per task for per-task weights).
+        Weight re-reads by the other workgroups are L2 traffic, not counted."""
+        pts = self.n_tasks * tiles_of(self.pts) * 32
+        per_pt = 0
+        fixed = 0
+        for o in self.ops:
+            if o.op in (L.OP_LOAD_PT, L.OP_STORE_PT, L.OP_ADD_PT, L.OP_MASK_POS, L.OP_ROWDOT_PT, L.OP_SOFTMAX_BWD):
+                per_pt += 4 * o.i0
+            elif o.op in (L.OP_LOAD_ROWS, L.OP_STORE_ROWS, L.OP_STORE_TR):
+                per_pt += 4 * o.i0
+            elif o.op == L.OP_SOFTMAX and o.i1:
+                per_pt += 8
+            elif o.op == L.OP_LINEAR:
+                if o.flags & (L.F_ADD_PT | L.F_MASK_PT):
+                    per_pt += 4 * pad32(o.i1)
+                per_task = o.i2 != L.W_ROWMAJOR or o.s0 != 0
+                fixed += 4 * o.i0 * o.i1 * (self.n_tasks if per_task else 1)
+        return per_pt * pts + fixed
+
     def launch(self) -> None:
         if not self.ops:
             return
@@ -134,7 +155,7 @@ class Program:
             ev0.record()
             self._launch()
             ev1.record()
-            PROFILE.append(("chain_kernel", self.flops(), ev0, ev1))
+            PROFILE.append(("chain_kernel", self.flops(), ev0, ev1, self.hbm_bytes()))
         else:
             self._launch()
 
@@ -159,7 +180,10 @@ def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
         ev0.record()
         _run_wgrad(jobs, n_tasks, pts, device)
         ev1.record()
-        PROFILE.append(("wgrad_kernel", sum(2 * j["N"] * j["K"] for j in jobs) * n_tasks * pts, ev0, ev1))
+        padded = n_tasks * tiles_of(pts) * 32
+        nbytes = sum(4 * (pad32(j["N"]) + pad32(j["K"])) * padded
+                     + 4 * j["N"] * j["K"] * (n_tasks if j.get("per_task") else 1) for j in jobs)
+        PROFILE.append(("wgrad_kernel", sum(2 * j["N"] * j["K"] for j in jobs) * n_tasks * pts, ev0, ev1, nbytes))
     else:
         _run_wgrad(jobs, n_tasks, pts, device)
 

@@ -23,14 +23,23 @@ def find(d, pat):
     return m[0] if m else None
 
 
+def kname(raw: str) -> str:
+    """'void npf::chain_kernel<16, 4>(npf_program)' -> 'npf::chain_kernel' (template instances pooled)."""
+    n = raw.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    for ch in "<(":
+        n = n.split(ch)[0]
+    return n.strip()
+
+
 def counters(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     f = find(d, "*counter_collection.csv")
     if not f:
         return out
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0]
-        out[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        out[kname(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return out
 
 
@@ -43,10 +52,13 @@ def main():
     if st:
         shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats.csv"))
         for row in csv.DictReader(open(st)):
-            name = row["Name"].split("(")[0]
+            name = kname(row["Name"])
             if name.startswith("npf::"):
-                summary["kernels"][name] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]),
-                                            "total_ns": float(row["TotalDurationNs"]), "pct": float(row["Percentage"])}
+                k = summary["kernels"].setdefault(name, {"calls": 0, "total_ns": 0.0, "pct": 0.0})
+                k["calls"] += int(row["Calls"])
+                k["total_ns"] += float(row["TotalDurationNs"])
+                k["pct"] += float(row["Percentage"])
+                k["avg_ns"] = k["total_ns"] / k["calls"]
     fetch, write, mfma = (counters(os.path.join(src, k)) for k in ("fetch", "write", "mfma"))
     for name in list(summary["kernels"]):
         k = summary["kernels"][name]
