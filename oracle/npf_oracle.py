@@ -44,10 +44,14 @@ class OracleConfig:
     is_heteroskedastic: bool = True
     is_q_zCct: bool = False
     z_dim: Optional[int] = None
+    attention: str = "scaledot"  # attentive kinds: "scaledot" | "multihead" | "transformer" (attention.py:16-86)
+    n_heads: int = 8
 
     def __post_init__(self):
         if self.kind not in MODEL_KINDS:
             raise ValueError(f"unknown kind {self.kind}")
+        if self.attention not in ("scaledot", "multihead", "transformer"):
+            raise ValueError(f"unknown attention {self.attention}")
         if self.encoded_path is None:
             self.encoded_path = {
                 "CNP": "deterministic",
@@ -95,6 +99,49 @@ def scaledot_attend(keys: torch.Tensor, queries: torch.Tensor, values: torch.Ten
     logits = torch.einsum("bkd,bqd->bqk", keys, queries) / math.sqrt(queries.size(-1))
     attn = logits.softmax(dim=-1)
     return torch.bmm(attn, values)
+
+
+def multihead_attend(params: Params, prefix: str, keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor,
+                     n_heads: int, post_process: bool = True) -> torch.Tensor:
+    """``MultiheadAttender.forward`` (npf/architectures/attention.py:456-527): K (no bias), Q
+    (bias), V (no bias) projections, heads stacked as extra batches (``_make_multiheaded``
+    :507-516: index h * B + b), scaled-dot attention per head with the *head* size in the
+    scale (:216-218), heads concatenated back (:518-527), optional post Linear (:500-503)."""
+    K = F.linear(keys, params[f"{prefix}.key_transform.weight"])
+    Q = F.linear(queries, params[f"{prefix}.query_transform.weight"], params[f"{prefix}.query_transform.bias"])
+    V = F.linear(values, params[f"{prefix}.value_transform.weight"])
+    B = keys.shape[0]
+    hs = K.shape[-1] // n_heads
+
+    def heads(x):
+        return x.view(B, -1, n_heads, hs).permute(2, 0, 1, 3).contiguous().view(B * n_heads, -1, hs)
+
+    ctx = scaledot_attend(heads(K), heads(Q), heads(V))
+    ctx = ctx.view(n_heads, B, -1, hs).permute(1, 2, 0, 3).contiguous().view(B, -1, n_heads * hs)
+    if post_process:
+        ctx = F.linear(ctx, params[f"{prefix}.post_processor.weight"], params[f"{prefix}.post_processor.bias"])
+    return ctx
+
+
+def transformer_attend(params: Params, prefix: str, keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor,
+                       n_heads: int) -> torch.Tensor:
+    """``TransformerAttender.forward`` (attention.py:566-588): multihead attention without the post
+    Linear, residual with the (untransformed) queries + LayerNorm, then residual MLP + LayerNorm."""
+    d = queries.shape[-1]
+    ctx = multihead_attend(params, prefix, keys, queries, values, n_heads, post_process=False)
+    ctx = F.layer_norm(ctx + queries, (d,), params[f"{prefix}.layer_norm1.weight"], params[f"{prefix}.layer_norm1.bias"])
+    ctx = F.layer_norm(ctx + mlp(params, f"{prefix}.mlp", ctx), (d,), params[f"{prefix}.layer_norm2.weight"],
+                       params[f"{prefix}.layer_norm2.bias"])
+    return ctx
+
+
+def attend(cfg: "OracleConfig", params: Params, keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor):
+    """``self.attender(keys, queries, values)`` of attnnp.py:128 for the configured flavour."""
+    if cfg.attention == "scaledot":
+        return scaledot_attend(keys, queries, values)
+    if cfg.attention == "multihead":
+        return multihead_attend(params, "attender", keys, queries, values, cfg.n_heads)
+    return transformer_attend(params, "attender", keys, queries, values, cfg.n_heads)
 
 
 def p_y_scale_transform(raw: torch.Tensor) -> torch.Tensor:
@@ -171,7 +218,7 @@ def trgt_dependent_representation(cfg, params, Xc_enc, z_samples, R, Xt_enc) -> 
     if Xc_enc.shape[1] == 0:
         R_det = torch.zeros(B, T, cfg.r_dim)
     else:
-        R_det = scaledot_attend(Xc_enc, Xt_enc, R)
+        R_det = attend(cfg, params, Xc_enc, Xt_enc, R)
     if cfg.kind == "AttnCNP":
         return R_det.unsqueeze(0)
     n_z = z_samples.size(0)
@@ -332,6 +379,8 @@ def model_shapes(cfg: OracleConfig, n_layers_xy: int = 2, n_layers_dec: int = 4)
     shapes += mlp_shapes("decoder.flat_module", r, 2 * dy, r, n_layers_dec)
     shapes += mlp_shapes("xy_encoder.resizer", dy, r, 32, 1)
     shapes += mlp_shapes("xy_encoder.flat_module", r, r, r, n_layers_xy, force_smaller=True)
+    if cfg.is_attentive and cfg.attention == "transformer":
+        shapes += mlp_shapes("attender.mlp", r, r, r, 1)  # attention.py:556-561
     if cfg.is_latent:
         shapes += mlp_shapes("latent_encoder", r, 2 * cfg.z_dim, r, 1)
         if cfg.encoded_path == "both":
@@ -364,6 +413,24 @@ def init_params(cfg: OracleConfig, seed: int = 0, n_layers_xy: int = 2, n_layers
             b = np.zeros((n_out,), dtype="float32")
         params[f"{name}.weight"] = torch.from_numpy(w)
         params[f"{name}.bias"] = torch.from_numpy(b)
+    if cfg.is_attentive and cfg.attention != "scaledot":
+        # attention.py:444-455: normal(0, sqrt(2 / (size + head_size))) for the three projections;
+        # LayerNorm weights are drawn away from 1 here so that parity tests exercise them
+        r = cfg.r_dim
+        std = math.sqrt(2.0 / (r + r // cfg.n_heads))
+        f32 = lambda a: torch.from_numpy(a.astype("float32"))  # noqa: E731
+        params["attender.key_transform.weight"] = f32(rng.normal(0.0, std, size=(r, r)))
+        params["attender.query_transform.weight"] = f32(rng.normal(0.0, std, size=(r, r)))
+        params["attender.query_transform.bias"] = f32(np.zeros((r,)))
+        params["attender.value_transform.weight"] = f32(rng.normal(0.0, std, size=(r, r)))
+        if cfg.attention == "multihead":
+            bound = 1.0 / math.sqrt(r)
+            params["attender.post_processor.weight"] = f32(rng.uniform(-bound, bound, size=(r, r)))
+            params["attender.post_processor.bias"] = f32(rng.uniform(-bound, bound, size=(r,)))
+        else:
+            for ln in ("layer_norm1", "layer_norm2"):
+                params[f"attender.{ln}.weight"] = f32(rng.uniform(0.5, 1.5, size=(r,)))
+                params[f"attender.{ln}.bias"] = f32(np.zeros((r,)))
     return params
 
 

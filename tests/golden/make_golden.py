@@ -73,9 +73,9 @@ def build_reference(case: dict):
     elif kind == "LNP":
         m = npf.LNP(case["dx"], case["dy"], encoded_path=case["encoded_path"], **kw)
     elif kind == "AttnCNP":
-        m = npf.AttnCNP(case["dx"], case["dy"], attention="scaledot", **kw)
+        m = npf.AttnCNP(case["dx"], case["dy"], attention=case.get("attention", "scaledot"), **kw)
     else:
-        m = npf.AttnLNP(case["dx"], case["dy"], attention="scaledot", **kw)
+        m = npf.AttnLNP(case["dx"], case["dy"], attention=case.get("attention", "scaledot"), **kw)
     return m
 
 
@@ -218,7 +218,44 @@ def run_pretrained():
     print("g7_pretrained_cnp: done; n_params", sum(v.numel() for v in sd.values()))
 
 
+def run_pretrained_attn():
+    """G9: the shipped RBF_Kernel AttnCNP / AttnLNP checkpoints (transformer attention, r = 128) on
+    seeded inputs, eval mode; AttnLNP with an injected eps (2 latent samples).  ``weights_only=True``."""
+    rng = np.random.Generator(np.random.Philox(9))
+    f = lambda a: torch.from_numpy(np.asarray(a, dtype="float32"))  # noqa: E731
+    B, C, T, r = 3, 25, 90, 128
+    Xc, Yc, Xt = f(rng.uniform(-1, 1, (B, C, 1))), f(rng.standard_normal((B, C, 1))), f(rng.uniform(-1, 1, (B, T, 1)))
+    eps = f(rng.standard_normal((2, B, 1, r)))
+    res = {"X_cntxt": Xc.numpy(), "Y_cntxt": Yc.numpy(), "X_trgt": Xt.numpy(), "eps": eps.numpy()}
+    kw = dict(r_dim=r, attention="transformer",
+              XYEncoder=merge_flat_input(partial(MLP, n_hidden_layers=2, hidden_size=r), is_sum_merge=True),
+              Decoder=merge_flat_input(partial(MLP, n_hidden_layers=4, hidden_size=r), is_sum_merge=True))
+    for tag, cls, extra in (("attncnp", npf.AttnCNP, {}),
+                            ("attnlnp", npf.AttnLNP, dict(n_z_samples_test=2, LatentDistribution=_latent_dist))):
+        sd = torch.load(os.path.join(REF, f"results/pretrained/RBF_Kernel/{cls.__name__}/run_0/params.pt"),
+                        map_location="cpu", weights_only=True)
+        model = cls(1, 1, **kw, **extra)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        _EpsIndependent.eps = eps
+        with torch.no_grad():
+            p, *_ = model(Xc, Yc, Xt)
+        res[f"{tag}_loc"], res[f"{tag}_scale"] = p.base_dist.loc.numpy(), p.base_dist.scale.numpy()
+        for k, v in sd.items():
+            res[f"{tag}_param/{k}"] = v.numpy()
+        print(f"g9 {tag}: n_params", sum(v.numel() for v in sd.values()), "loc", p.base_dist.loc.shape)
+    np.savez_compressed(os.path.join(HERE, "g9_pretrained_attn.npz"), **res)
+
+
 if __name__ == "__main__":
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    if only:  # e.g. `make_golden.py g8_ g9` regenerates the matching cases only
+        for name, case in specs.CASES.items():
+            if any(name.startswith(o) for o in only):
+                run_case(name, case, store_params=False, store_full_grads=case["r"] < 256)
+        if any(o.startswith("g9") for o in only):
+            run_pretrained_attn()
+        sys.exit(0)
     small_full = {"g1_cnp_c1", "g2_lnp_both_c1", "g2_lnp_latent_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64",
                   "g4s_attnlnp_r64_noqzcct"}
     for name, case in specs.CASES.items():
@@ -228,3 +265,4 @@ if __name__ == "__main__":
     run_decode_case()
     run_stage_cases()
     run_pretrained()
+    run_pretrained_attn()

@@ -47,6 +47,13 @@ CASES = {
     "g6_cnp_c0": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=0, T=16),
     "g6_attncnp_c0": dict(kind="AttnCNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=0, T=16),
     "g6_attncnp_r128": dict(kind="AttnCNP", r=128, L_xy=2, L_dec=4, dx=1, dy=1, B=2, C=50, T=128),
+    # G8: learned-projection attention, what the reference's notebooks and shipped
+    # Attn* checkpoints use
+    "g8_attncnp_multihead": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=45, attention="multihead"),
+    "g8_attncnp_transformer": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=45,
+                                   attention="transformer"),
+    "g8_attnlnp_transformer": dict(kind="AttnLNP", r=128, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=33, T=40,
+                                   attention="transformer", is_q_zCct=True, n_z=2),
 }
 
 # G5: decode-only, config-5 decoder (r=512, L=4) at reduced batch
@@ -57,7 +64,7 @@ def cfg_of(case: dict) -> O.OracleConfig:
     return O.OracleConfig(
         kind=case["kind"], x_dim=case["dx"], y_dim=case["dy"], r_dim=case["r"],
         encoded_path=case.get("encoded_path"), is_heteroskedastic=case.get("is_heteroskedastic", True),
-        is_q_zCct=case.get("is_q_zCct", False),
+        is_q_zCct=case.get("is_q_zCct", False), attention=case.get("attention", "scaledot"),
     )
 
 

@@ -146,3 +146,19 @@ def test_oracle_pretrained_cnp():
                     torch.from_numpy(g["X_trgt"]), training=False)
     assert np.array_equal(out["loc"].numpy(), g["cnp_loc"])
     assert np.array_equal(out["scale"].numpy(), g["cnp_scale"])
+
+
+def test_oracle_pretrained_attn_checkpoints():
+    """G9: the shipped RBF_Kernel AttnCNP / AttnLNP checkpoints (transformer attention, r = 128),
+    eval mode, against the reference's own outputs."""
+    g = specs.load_golden("g9_pretrained_attn")
+    Xc, Yc, Xt = (torch.from_numpy(g[k]) for k in ("X_cntxt", "Y_cntxt", "X_trgt"))
+    for tag, kind in (("attncnp", "AttnCNP"), ("attnlnp", "AttnLNP")):
+        params = {k[len(tag) + 7:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"{tag}_param/")}
+        cfg = O.OracleConfig(kind=kind, x_dim=1, y_dim=1, r_dim=128, attention="transformer")
+        out = O.forward(cfg, params, Xc, Yc, Xt, None, eps=torch.from_numpy(g["eps"]) if kind == "AttnLNP" else None,
+                        n_z=2, training=False)
+        for key in ("loc", "scale"):
+            got, ref = out[key].detach().numpy(), g[f"{tag}_{key}"]
+            assert got.shape == ref.shape
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(), err_msg=f"{tag} {key}")
