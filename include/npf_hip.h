@@ -20,6 +20,8 @@
  *   npf_mean_agg_fwd/bwd torch.mean(R_cntxt, dim=1)       npf/neuralproc/np.py:95, attnnp.py:181
  *   npf_pack_pt/unpack_pt  layout change at the module boundary (no reference counterpart)
  *   npf_transpose        W -> W^T for the dgrad chains (no reference counterpart)
+ *   npf_split_heads/npf_merge_heads  MultiheadAttender._make_multiheaded / _concatenate_multiheads
+ *                                                         npf/architectures/attention.py:505-527
  *
  * Conventions: plain device pointers + sizes, caller owns all memory, every call is
  * asynchronous on `stream` (a hipStream_t passed as void*), returns 0 on success and a
@@ -69,9 +71,15 @@ enum npf_opcode {
   NPF_OP_SOFTMAX_BWD = 11, /* cur <- f0 * P * (cur - acc0), P = PT32 p0 (i0 = F)                */
   NPF_OP_RELU = 12,        /* cur <- max(cur, 0)                                                */
   NPF_OP_SCALE = 13,       /* cur <- f0 * cur                                                   */
-  NPF_OP_STORE_TR = 14     /* row-major p0 [task][i0 features][i1 >= 32*tiles points] <- cur: a
+  NPF_OP_STORE_TR = 14,    /* row-major p0 [task][i0 features][i1 >= 32*tiles points] <- cur: a
                               feature-major copy, i.e. the activations as NPF_W_ROWMAJOR per-task
                               weights W[n = feature][k = point] (s0 = i0*i1, i3 = i1)            */
+  NPF_OP_LAYERNORM = 15,   /* cur <- (cur - mean) / sqrt(var + f0) * p0[f] + p1[f] over the i0 <= 256
+                              features of the point (nn.LayerNorm of TransformerAttender,
+                              npf/architectures/attention.py:552-553,583-586)                    */
+  NPF_OP_LAYERNORM_BWD = 16 /* cur = dy on entry; x = PT32 p0 (the forward input, i0 = F), gamma p1:
+                              xhat = (x - mean) rstd;  PT32 p2 <- dy * xhat (for dgamma);
+                              cur <- rstd (g - mean(g) - xhat mean(g xhat)),  g = dy * gamma      */
 };
 
 enum npf_wmode {
@@ -178,6 +186,14 @@ int npf_unpack_pt(const float *pt, int32_t n_tasks, int32_t pts_per_task, int32_
                   void *stream);
 /* dst[c][r] = src[r][c] for a row-major [rows][cols] matrix. */
 int npf_transpose(const float *src, int32_t rows, int32_t cols, float *dst, void *stream);
+/* Heads as tasks (MultiheadAttender._make_multiheaded / _concatenate_multiheads,
+ * npf/architectures/attention.py:505-527) on PT32 tensors:
+ *   split:  dst PT32 [n_heads*n_tasks][pts][F/n_heads]:  dst(h*n_tasks + b, p, f) = src(b, p, h*(F/n_heads) + f)
+ *   merge:  the inverse (dst PT32 [n_tasks][pts][F]).  F % n_heads == 0 and (F/n_heads) % 4 == 0. */
+int npf_split_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int32_t F, int32_t n_heads, float *dst,
+                    void *stream);
+int npf_merge_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int32_t F, int32_t n_heads, float *dst,
+                    void *stream);
 
 /* Library / device info. */
 int npf_version(void);

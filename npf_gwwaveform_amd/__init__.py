@@ -4,7 +4,8 @@ MarinerQ/npf_GWwaveform, behind the reference's own module API.  See DESIGN.md.
 The compute runs in hand-written HIP kernels (``csrc/``) reached through a C ABI
 (``include/npf_hip.h``); there is no CPU or eager-PyTorch fallback for the path.
 """
-from .architectures import MLP, DotAttender, MergeFlatInputs, get_attender, merge_flat_input
+from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, TransformerAttender, get_attender,
+                            merge_flat_input)
 from .losses import CNPFLoss, ELBOLossLNPF, NLLLossLNPF
 from .neuralproc import (CNP, LNP, AttnCNP, AttnLNP, LatentNeuralProcessFamily, MultivariateNormalDiag,
                          NeuralProcessFamily)
@@ -31,7 +32,7 @@ def decode(model: NeuralProcessFamily, X_trgt_enc, R_trgt):
 
 
 __all__ = [
-    "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "get_attender",
+    "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "get_attender",
     "NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP", "NPFModel",
     "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "MultivariateNormalDiag", "encode", "aggregate", "decode",
 ]

@@ -20,7 +20,7 @@ NPF_MAX_TRAIN_FEATURES = 256  # widest layer side with a backward pass (npf_wgra
 
 # opcodes (enum npf_opcode)
 OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFTMAX, OP_ADD_PT, OP_MASK_POS, \
-    OP_ADD_TASKVEC, OP_ROWDOT_PT, OP_SOFTMAX_BWD, OP_RELU, OP_SCALE, OP_STORE_TR = range(15)
+    OP_ADD_TASKVEC, OP_ROWDOT_PT, OP_SOFTMAX_BWD, OP_RELU, OP_SCALE, OP_STORE_TR, OP_LAYERNORM, OP_LAYERNORM_BWD = range(17)
 # weight modes (enum npf_wmode)
 W_ROWMAJOR, W_PT_ROWS, W_PT_COLS = range(3)
 F_RELU, F_ADD_PT, F_MASK_PT = 1, 2, 4
@@ -66,6 +66,8 @@ SIGNATURES = {
     "npf_pack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "npf_unpack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "npf_transpose": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "npf_split_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "npf_merge_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_version": (C.c_int, []),
 }
 

@@ -28,7 +28,8 @@ from . import functional as FN
 from ._lib import NPF_MAX_TRAIN_FEATURES
 from .chain import Chain
 
-__all__ = ["MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "get_attender"]
+__all__ = ["MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender",
+           "get_attender"]
 
 
 def _check_relu(activation) -> None:
@@ -232,6 +233,110 @@ class DotAttender(nn.Module):
         return FN.unpack_pt(o, T, self.out_size)
 
 
+class MultiheadAttender(nn.Module):
+    """Multihead attention (npf/architectures/attention.py:375-527): K (no bias) / Q (bias) / V (no
+    bias) projections, ``n_heads`` scaled-dot attentions on the head slices (heads stacked as extra
+    tasks, scale 1/sqrt(head size)), concatenation, optional post Linear.  Same parameter names as
+    the reference: ``key_transform``, ``query_transform``, ``value_transform``, ``post_processor``."""
+
+    def __init__(self, kq_size, value_size, out_size, n_heads=8, is_post_process=True, dropout=0, is_relative_pos=False):
+        super().__init__()
+        if dropout != 0 or is_relative_pos:
+            raise NotImplementedError("attention dropout / relative positions are not on the hot path")
+        if kq_size != value_size:
+            raise NotImplementedError("the HIP path needs kq_size == value_size (always the case in AttnCNP / AttnLNP)")
+        assert kq_size % n_heads == 0, "{} % {} != 0".format(kq_size, n_heads)
+        assert value_size % n_heads == 0, "{} % {} != 0".format(value_size, n_heads)
+        if (kq_size // n_heads) % 4 != 0:
+            raise NotImplementedError("head size must be a multiple of 4 on the HIP path")
+        self.is_relative_pos = False
+        self.key_transform = nn.Linear(kq_size, kq_size, bias=False)
+        self.query_transform = nn.Linear(kq_size, kq_size, bias=True)
+        self.value_transform = nn.Linear(value_size, value_size, bias=False)
+        self.n_heads = n_heads
+        self.kq_head_size = kq_size // n_heads
+        self.value_head_size = kq_size // n_heads
+        self.kq_size, self.value_size, self.out_size = kq_size, value_size, out_size
+        self.dot = DotAttender(self.kq_head_size, self.value_head_size, self.value_head_size, is_scale=True)
+        self.post_processor = nn.Linear(value_size, out_size) if is_post_process or value_size != out_size else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # attention.py:444-455 (weights_init itself is a no-op, SURVEY.md 8a row 12)
+        std = math.sqrt(2.0 / (self.kq_size + self.kq_head_size))
+        nn.init.normal_(self.key_transform.weight, mean=0, std=std)
+        nn.init.normal_(self.query_transform.weight, mean=0, std=std)
+        std = math.sqrt(2.0 / (self.value_size + self.value_head_size))
+        nn.init.normal_(self.value_transform.weight, mean=0, std=std)
+
+    # -- PT32 level
+    def _project(self, x_pt, n_tasks, pts, lin):
+        ch = Chain(n_tasks, pts, x_pt.device)
+        ch.input_pt(x_pt, lin.in_features).linear(lin.weight, lin.bias).output_pt()
+        return ch.run()[0]
+
+    def _heads_attention(self, queries_pt, keys_pt, values_pt, B, C, T):
+        """K/Q/V projections, per-head scaled-dot attention, heads merged: PT32 [B, T, value_size]."""
+        H, d = self.n_heads, self.kq_size
+        Kh = FN.split_heads(self._project(keys_pt, B, C, self.key_transform), B, C, d, H)
+        Qh = FN.split_heads(self._project(queries_pt, B, T, self.query_transform), B, T, d, H)
+        Vh = FN.split_heads(self._project(values_pt, B, C, self.value_transform), B, C, self.value_size, H)
+        if self.dot.fits_fused(C):
+            ch = Chain(H * B, T, queries_pt.device, wg_per_task=True)
+            ch.input_pt(Qh, self.kq_head_size)
+            self.dot.append_to(ch, Kh, Vh, C).output_pt()
+            Oh = ch.run()[0]
+        else:
+            Oh = self.dot.attend_pt(Qh, Kh, Vh, C, T)
+        return FN.merge_heads(Oh, B, T, self.value_size, H)
+
+    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
+        B = queries_pt.shape[0]
+        ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, n_queries)
+        if self.post_processor is not None:
+            ctx = self._project(ctx, B, n_queries, self.post_processor)
+        return ctx
+
+    def forward(self, keys, queries, values, rel_pos_enc=None, **kwargs):
+        if rel_pos_enc is not None or keys.dim() != 3:
+            raise NotImplementedError("relative position encodings are not on the hot path")
+        C, T = keys.shape[1], queries.shape[1]
+        if C == 0:
+            raise ValueError("attention over zero keys")
+        o = self.attend_pt(FN.pack_pt(queries), FN.pack_pt(keys), FN.pack_pt(values), C, T)
+        return FN.unpack_pt(o, T, self.out_size)
+
+
+class TransformerAttender(MultiheadAttender):
+    """Image-transformer style attention (attention.py:530-588): multihead attention without the
+    post Linear, ``LayerNorm(context + queries)``, then ``LayerNorm(x + MLP(x))``.  This is what the
+    reference's notebooks and every shipped ``Attn*`` checkpoint use."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, is_post_process=False, **kwargs)
+        assert self.kq_size == self.out_size
+        self.layer_norm1 = nn.LayerNorm(self.out_size)
+        self.layer_norm2 = nn.LayerNorm(self.out_size)
+        self.mlp = MLP(self.out_size, self.out_size, hidden_size=self.out_size, activation=nn.ReLU())
+        self.reset_parameters()
+
+    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
+        B, T, d = queries_pt.shape[0], n_queries, self.out_size
+        ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, T)
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        ch = Chain(B, T, queries_pt.device)
+        ch.input_pt(ctx, d).add_pt(queries_pt).layernorm(ln1.weight, ln1.bias, ln1.eps).output_pt()
+        x = ch.run()[0]
+        # (the residual re-reads x, so the MLP block is its own launch)
+        ls = self.mlp.layers()
+        ch = Chain(B, T, queries_pt.device)
+        ch.input_pt(x, d)
+        for lin in ls[:-1]:
+            ch.linear(lin.weight, lin.bias, relu=True)
+        ch.linear(ls[-1].weight, ls[-1].bias, addend=x).layernorm(ln2.weight, ln2.bias, ln2.eps).output_pt()
+        return ch.run()[0]
+
+
 def get_attender(attention, kq_size, value_size, out_size, **kwargs):
     """``get_attender`` of npf/architectures/attention.py:16-86 for the hot path."""
     if not isinstance(attention, str):
@@ -239,7 +344,11 @@ def get_attender(attention, kq_size, value_size, out_size, **kwargs):
     attention = attention.lower()
     if attention == "scaledot":
         return DotAttender(kq_size, value_size, out_size, is_scale=True, **kwargs)
-    if attention in ("multiplicative", "additive", "cosine", "manhattan", "euclidean", "weighted_dist", "multihead",
-                     "transformer"):
-        raise NotImplementedError(f"attention={attention!r} is not on the MI355X hot path yet (scaledot only)")
+    if attention == "multihead":
+        return MultiheadAttender(kq_size, value_size, out_size, **kwargs)
+    if attention == "transformer":
+        return TransformerAttender(kq_size, value_size, out_size, **kwargs)
+    if attention in ("multiplicative", "additive", "cosine", "manhattan", "euclidean", "weighted_dist"):
+        raise NotImplementedError(f"attention={attention!r} is not on the MI355X hot path "
+                                  "(scaledot, multihead, transformer are)")
     raise ValueError("Unknown attention method {}".format(attention))

@@ -111,6 +111,12 @@ class Program:
         """mode 1: also store (row max, row sum) to ``stats`` [n_tasks, pts, 2]; mode 2: take them from it."""
         self._op(op=L.OP_SOFTMAX, i0=n_valid, i1=mode, f0=scale, p0=self._p(stats))
 
+    def layernorm(self, gamma, beta, F, eps):
+        self._op(op=L.OP_LAYERNORM, i0=F, f0=eps, p0=self._p(gamma), p1=self._p(beta))
+
+    def layernorm_bwd(self, x_saved, gamma, F, eps, dy_xhat=None):
+        self._op(op=L.OP_LAYERNORM_BWD, i0=F, f0=eps, p0=self._p(x_saved), p1=self._p(gamma), p2=self._p(dy_xhat))
+
     def add_taskvec(self, t, F, relu=False, modulus=0):
         self._op(op=L.OP_ADD_TASKVEC, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
 
@@ -140,6 +146,8 @@ class Program:
                 per_pt += 4 * o.i0
             elif o.op == L.OP_SOFTMAX and o.i1:
                 per_pt += 8
+            elif o.op == L.OP_LAYERNORM_BWD:
+                per_pt += 4 * pad32(o.i0) * (2 if o.p2 else 1)
             elif o.op == L.OP_LINEAR:
                 if o.flags & (L.F_ADD_PT | L.F_MASK_PT):
                     per_pt += 4 * pad32(o.i1)
@@ -287,6 +295,13 @@ class Chain:
         self.steps.append(_Step("add_taskvec", {"v": self._t(v)}, {"F": self.F, "relu": relu, "mod": modulus}))
         return self
 
+    def layernorm(self, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> "Chain":
+        """cur <- LayerNorm(cur) over the features (nn.LayerNorm with affine parameters)."""
+        if self.F > L.NPF_MAX_TRAIN_FEATURES or weight.shape != (self.F,) or bias.shape != (self.F,):
+            raise ValueError(f"LayerNorm over {self.F} features with parameters {tuple(weight.shape)}")
+        self.steps.append(_Step("layernorm", {"g": self._t(weight), "b": self._t(bias)}, {"F": self.F, "eps": float(eps)}))
+        return self
+
     def attn_scores(self, keys_pt: torch.Tensor, n_keys: int, keys_tr: Optional[torch.Tensor] = None) -> "Chain":
         """cur[c] <- sum_d keys[c][d] cur[d] (DotAttender.score, attention.py:204-220, unscaled).
         ``keys_tr``: optional feature-major copy [n_tasks, d, 32*tiles] of the keys (``store_tr``):
@@ -405,6 +420,13 @@ class _ChainFn(torch.autograd.Function):
                 upstream = upstream or needs_grad[st.t["v"]]
                 if train and a["relu"] and upstream:
                     saved[(i, "out")] = ensure_saved(a["F"])
+            elif k == "layernorm":
+                gi, bi = st.t["g"], st.t["b"]
+                upstream = upstream or needs_grad[gi] or needs_grad[bi]
+                if train and upstream:
+                    saved[(i, "in")] = ensure_saved(a["F"])
+                prog.layernorm(T[gi].contiguous(), T[bi].contiguous(), a["F"], a["eps"])
+                backed = None
             elif k == "attn_scores":
                 kk = st.t["k"]
                 if train and needs_grad[kk]:
@@ -460,6 +482,7 @@ class _ChainFn(torch.autograd.Function):
         prog = Program(chain.n_tasks, chain.pts, chain.wg_per_task)
         grads: List[Optional[torch.Tensor]] = [None] * len(T)
         pending_taskvec = []  # (tensor index, PT buffer, F, modulus): reduced over the points after the launch
+        pending_vec = []      # (tensor index, PT buffer, F): reduced over points and tasks (LayerNorm gamma / beta)
         jobs = []
         gouts = list(gouts)
         started = False  # has cur been initialised with a gradient yet
@@ -535,6 +558,17 @@ class _ChainFn(torch.autograd.Function):
                         grads[idx] = (buf, a["mod"])
                     else:
                         pending_taskvec.append((idx, buf, a["F"], a["mod"]))
+            elif k == "layernorm":
+                gi, bi = st.t["g"], st.t["b"]
+                dyx = None
+                if needs_grad[bi]:
+                    dyb = new_pt(a["F"])
+                    prog.store_pt(dyb, a["F"])
+                    pending_vec.append((bi, dyb, a["F"]))
+                if needs_grad[gi]:
+                    dyx = new_pt(a["F"])
+                    pending_vec.append((gi, dyx, a["F"]))
+                prog.layernorm_bwd(saved[(i, "in")], T[gi].contiguous(), a["F"], a["eps"], dy_xhat=dyx)
             elif k == "attn_values":
                 vv = st.t["v"]
                 if needs_grad[vv]:
@@ -579,6 +613,8 @@ class _ChainFn(torch.autograd.Function):
         for idx, buf, F, mod in pending_taskvec:
             g = sum_points_pt(buf, chain.pts, F)  # [n_tasks, pad32(F)]
             acc_grad(idx, reduce_modulus(g, mod))
+        for idx, buf, F in pending_vec:
+            acc_grad(idx, sum_points_pt(buf, chain.pts, F).sum(0)[:F])
         out = []
         for g in grads:
             if isinstance(g, tuple):

@@ -818,6 +818,85 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
 #pragma unroll
       for (int b = 0; b < kMaxB16; ++b)
         if (b < FB) cur[b] *= inv;
+    } else if (opc == NPF_OP_LAYERNORM || opc == NPF_OP_LAYERNORM_BWD) {
+      if constexpr (MAXB == 16) {
+        // nn.LayerNorm over the F valid features of the point (biased variance, eps inside the root).
+        // Forward: cur = x.  Backward: cur = dy, x reloaded from the saved forward input.
+        const int F = o.i0, FB = ((F + 31) >> 5) * 2;
+        const float invF = 1.f / (float)F, eps = o.f0;
+        const bool bwd = opc == NPF_OP_LAYERNORM_BWD;
+        const float* gam = (const float*)o.p1;
+        if (!bwd) gam = (const float*)o.p0;
+        const float* bet = (const float*)o.p1;  // forward only
+        const float* xt = bwd ? pt_lane(o.p0, g, w, ((F + 31) >> 5) * 32, 0) : Z;
+        f32x4 x[kMaxB16];
+        float s1 = 0.f;
+#pragma unroll
+        for (int b = 0; b < kMaxB16; ++b) {
+          x[b] = zero4;
+          if (b < FB) {
+            if (bwd) {
+              if (w.valid) x[b] = *(const f32x4*)(xt + (4 * b + w.g) * 128);
+            } else {
+              x[b] = cur[b];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (16 * b + 4 * w.g + e < F) s1 += x[b][e];
+          }
+        }
+        const float mean = xg_sum(s1) * invF;
+        float s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < kMaxB16; ++b)
+          if (b < FB)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool ok = 16 * b + 4 * w.g + e < F;
+              const float d = ok ? x[b][e] - mean : 0.f;
+              x[b][e] = d;
+              s2 += d * d;
+            }
+        const float rstd = 1.f / sqrtf(xg_sum(s2) * invF + eps);
+        if (!bwd) {
+#pragma unroll
+          for (int b = 0; b < kMaxB16; ++b)
+            if (b < FB)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int f = 16 * b + 4 * w.g + e;
+                cur[b][e] = f < F ? x[b][e] * rstd * gam[f] + bet[f] : 0.f;
+              }
+        } else {
+          float* xo = o.p2 ? (float*)pt_lane(o.p2, g, w, ((F + 31) >> 5) * 32, 0) : nullptr;
+          float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+          for (int b = 0; b < kMaxB16; ++b)
+            if (b < FB) {
+              f32x4 dyx;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int f = 16 * b + 4 * w.g + e;
+                const float xh = x[b][e] * rstd;  // 0 on padding features
+                const float gg = f < F ? cur[b][e] * gam[f] : 0.f;
+                dyx[e] = cur[b][e] * xh;
+                x[b][e] = xh;
+                cur[b][e] = gg;
+                m1 += gg;
+                m2 += gg * xh;
+              }
+              if (xo && w.valid) *(f32x4*)(xo + (4 * b + w.g) * 128) = dyx;
+            }
+          m1 = xg_sum(m1) * invF;
+          m2 = xg_sum(m2) * invF;
+#pragma unroll
+          for (int b = 0; b < kMaxB16; ++b)
+            if (b < FB)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                cur[b][e] = (16 * b + 4 * w.g + e < F) ? rstd * (cur[b][e] - m1 - x[b][e] * m2) : 0.f;
+        }
+      }
     } else if (opc == NPF_OP_ADD_TASKVEC) {
       const int FB = o.i0 >> 4;
       const float* v = (const float*)o.p0 + (size_t)eff_task(w, o.i4) * o.i0;
@@ -893,6 +972,14 @@ static int validate(const npf_program_t* g) {
         break;
       case NPF_OP_STORE_TR:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || !o.p0 || o.i1 < g->tiles_per_task * 32) return NPF_EINVAL;
+        break;
+      case NPF_OP_LAYERNORM:
+        if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 || !(o.f0 > 0.f)) return NPF_EINVAL;
+        break;
+      case NPF_OP_LAYERNORM_BWD:
+        if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 || (((uintptr_t)o.p0) & 15) || (((uintptr_t)o.p2) & 15) ||
+            !(o.f0 > 0.f))
+          return NPF_EINVAL;
         break;
       case NPF_OP_RELU:
       case NPF_OP_SCALE:

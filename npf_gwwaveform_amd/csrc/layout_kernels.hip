@@ -49,6 +49,46 @@ __global__ void unpack_pt_kernel(const float* __restrict__ pt, int n_tasks, int 
   }
 }
 
+// Heads as tasks and back (attention.py:505-527), one float4 of the *head-split* tensor per thread.
+// SPLIT: hs[h*B + b][p][f] = full[b][p][h*hsz + f];  !SPLIT: the inverse.  Padding quads of the
+// destination are written as zeros.
+template <bool SPLIT>
+__global__ void heads_kernel(const float* __restrict__ src, int n_tasks, int pts, int Fp, int hsz, int n_heads,
+                             float* __restrict__ dst) {
+  const int tiles = (pts + 31) / 32;
+  const int hq = ((hsz + 31) / 32) * 8;  // quads per point of the head tensor (padded to 32 features)
+  const int fq = Fp / 4;
+  if (SPLIT) {
+    const size_t total = (size_t)n_heads * n_tasks * tiles * hq * 32;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+      const int p = idx & 31;
+      const size_t r = idx >> 5;
+      const int q = r % hq;
+      const size_t tt = r / hq;
+      const int tile = tt % tiles;
+      const size_t ht = tt / tiles;  // h * n_tasks + b
+      const int h = ht / n_tasks, b = ht - (size_t)h * n_tasks;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (4 * q < hsz) v = *(const f32x4*)(src + ((((size_t)b * tiles + tile) * fq + (h * hsz) / 4 + q) * 32 + p) * 4);
+      *(f32x4*)(dst + idx * 4) = v;
+    }
+  } else {
+    const size_t total = (size_t)n_tasks * tiles * fq * 32;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+      const int p = idx & 31;
+      const size_t r = idx >> 5;
+      const int q = r % fq;
+      const size_t tt = r / fq;
+      const int tile = tt % tiles;
+      const size_t b = tt / tiles;
+      const int h = (4 * q) / hsz, qh = q - (h * hsz) / 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (h < n_heads) v = *(const f32x4*)(src + (((((size_t)h * n_tasks + b) * tiles + tile) * hq + qh) * 32 + p) * 4);
+      *(f32x4*)(dst + idx * 4) = v;
+    }
+  }
+}
+
 // 32x32 LDS tile transpose
 __global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
   __shared__ float tile[32][33];
@@ -133,6 +173,35 @@ extern "C" int npf_transpose(const float* src, int32_t rows, int32_t cols, float
                      src, rows, cols, dst);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
+}
+
+static int heads_launch(bool split, const float* src, int32_t n_tasks, int32_t pts, int32_t F, int32_t n_heads, float* dst,
+                        void* stream) {
+  if (!src || !dst || n_tasks <= 0 || pts <= 0 || F <= 0 || n_heads <= 0 || F % n_heads) return NPF_EINVAL;
+  const int hsz = F / n_heads;
+  if (hsz & 3) return NPF_EINVAL;
+  const int Fp = npf::round_up(F, 32), tiles = (pts + 31) / 32;
+  if (split) {
+    const size_t total = (size_t)n_heads * n_tasks * tiles * (npf::round_up(hsz, 32) / 4) * 32;
+    hipLaunchKernelGGL(npf::heads_kernel<true>, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       n_tasks, pts, Fp, hsz, n_heads, dst);
+  } else {
+    const size_t total = (size_t)n_tasks * tiles * (Fp / 4) * 32;
+    hipLaunchKernelGGL(npf::heads_kernel<false>, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       n_tasks, pts, Fp, hsz, n_heads, dst);
+  }
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_split_heads(const float* src, int32_t n_tasks, int32_t pts, int32_t F, int32_t n_heads, float* dst,
+                               void* stream) {
+  return heads_launch(true, src, n_tasks, pts, F, n_heads, dst, stream);
+}
+
+extern "C" int npf_merge_heads(const float* src, int32_t n_tasks, int32_t pts, int32_t F, int32_t n_heads, float* dst,
+                               void* stream) {
+  return heads_launch(false, src, n_tasks, pts, F, n_heads, dst, stream);
 }
 
 extern "C" int npf_mean_agg_fwd(const float* R_pt, int32_t n_tasks, int32_t pts, int32_t F, float* out, void* stream) {

@@ -136,3 +136,42 @@ def gauss_head(suff: torch.Tensor, Y: Optional[torch.Tensor], dy: int, homoskeda
     (npf/neuralproc/base.py:350-365; losses.py:18-24).  ``sum_log_prob`` [rows] is the
     log-likelihood of ``Y`` [rows or B, pts, dy] summed over targets and y-dims."""
     return _GaussHeadFn.apply(suff, Y, dy, homoskedastic)
+
+
+class _HeadsFn(torch.autograd.Function):
+    """Heads as tasks and back on PT32 tensors (attention.py:505-527); the two directions are each
+    other's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x_pt, n_tasks, pts, F, n_heads, split):
+        ctx.geom = (n_tasks, pts, F, n_heads, split)
+        return _heads(x_pt, n_tasks, pts, F, n_heads, split)
+
+    @staticmethod
+    def backward(ctx, g):
+        n_tasks, pts, F, n_heads, split = ctx.geom
+        return _heads(g.contiguous(), n_tasks, pts, F, n_heads, not split), None, None, None, None, None
+
+
+def _heads(x_pt, n_tasks, pts, F, n_heads, split):
+    from .chain import pt_empty
+
+    lib = L.load()
+    x_pt = x_pt.contiguous()
+    if split:
+        out = pt_empty(n_heads * n_tasks, pts, F // n_heads, x_pt.device)
+        L.check(lib.npf_split_heads(L.ptr(x_pt), n_tasks, pts, F, n_heads, L.ptr(out), L.stream_ptr()), "npf_split_heads")
+    else:
+        out = pt_empty(n_tasks, pts, F, x_pt.device)
+        L.check(lib.npf_merge_heads(L.ptr(x_pt), n_tasks, pts, F, n_heads, L.ptr(out), L.stream_ptr()), "npf_merge_heads")
+    return out
+
+
+def split_heads(x_pt: torch.Tensor, n_tasks: int, pts: int, F: int, n_heads: int) -> torch.Tensor:
+    """PT32 [n_tasks, pts, F] -> PT32 [n_heads * n_tasks, pts, F / n_heads] (task index h * n_tasks + b)."""
+    return _HeadsFn.apply(x_pt, n_tasks, pts, F, n_heads, True)
+
+
+def merge_heads(x_pt: torch.Tensor, n_tasks: int, pts: int, F: int, n_heads: int) -> torch.Tensor:
+    """Inverse of :func:`split_heads`."""
+    return _HeadsFn.apply(x_pt, n_tasks, pts, F, n_heads, False)

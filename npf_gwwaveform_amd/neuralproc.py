@@ -26,7 +26,7 @@ import torch.nn as nn
 from torch.distributions import Independent, Normal
 
 from . import functional as FN
-from .architectures import MLP, DotAttender, MergeFlatInputs, get_attender, merge_flat_input
+from .architectures import MLP, DotAttender, MergeFlatInputs, MultiheadAttender, get_attender, merge_flat_input
 from .chain import Chain, pad32
 
 __all__ = ["NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP",
@@ -406,8 +406,8 @@ class AttnCNP(NeuralProcessFamily):
         if not isinstance(self.xy_encoder, MergeFlatInputs):
             raise NotImplementedError("the HIP path needs the stock merge_flat_input(MLP) XYEncoder")
         self.attender = get_attender(attention, self.x_transf_dim, self.r_dim, self.r_dim, **attention_kwargs)
-        if not isinstance(self.attender, DotAttender):
-            raise NotImplementedError("the HIP path implements attention='scaledot' only")
+        if not isinstance(self.attender, (DotAttender, MultiheadAttender)):
+            raise NotImplementedError("the HIP path implements attention = 'scaledot', 'multihead', 'transformer'")
 
     dflt_Modules = CNP.dflt_Modules
 
@@ -437,7 +437,9 @@ class AttnCNP(NeuralProcessFamily):
         """cur of ``ch`` <- attention of the targets over the context (attnnp.py:118-131): fused into
         the chain while a score row fits the registers, blocked (attention_long.py) beyond that."""
         k_tr, v_tr = getattr(Xc_pt, "_npf_tr", None), getattr(R, "_npf_tr", None)
-        if self.attender.fits_fused(C):
+        if not isinstance(self.attender, DotAttender):  # learned projections: its own launches
+            ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T), self.r_dim)
+        elif self.attender.fits_fused(C):
             ch.input_pt(Xt_pt, self.x_transf_dim)
             self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr)
         else:

@@ -241,6 +241,13 @@ def run_pretrained_attn():
         with torch.no_grad():
             p, *_ = model(Xc, Yc, Xt)
         res[f"{tag}_loc"], res[f"{tag}_scale"] = p.base_dist.loc.numpy(), p.base_dist.scale.numpy()
+        # the same model evaluated by the reference in float64: trained weights make this forward pass
+        # ill-conditioned (the fp32 result is ~1e-4 of max|loc| away from the exact one), so parity
+        # tests on these checkpoints are stated against the fp64 value
+        _EpsIndependent.eps = eps.double()
+        with torch.no_grad():
+            p64, *_ = model.double()(Xc.double(), Yc.double(), Xt.double())
+        res[f"{tag}_loc64"], res[f"{tag}_scale64"] = p64.base_dist.loc.numpy(), p64.base_dist.scale.numpy()
         for k, v in sd.items():
             res[f"{tag}_param/{k}"] = v.numpy()
         print(f"g9 {tag}: n_params", sum(v.numel() for v in sd.values()), "loc", p.base_dist.loc.shape)

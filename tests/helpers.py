@@ -42,6 +42,8 @@ def build_model(case: dict, device="cuda:0", params=None):
                   LatentDistribution=eps_latent_dist)
     if kind == "LNP":
         kw["encoded_path"] = case["encoded_path"]
+    if "attention" in case:
+        kw["attention"] = case["attention"]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = getattr(A, kind)(case["dx"], case["dy"], **kw)

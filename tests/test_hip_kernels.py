@@ -214,3 +214,45 @@ def test_cpu_tensor_is_rejected_loudly():
     CH, FN = _mods()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         FN.pack_pt(torch.zeros(1, 4, 4))
+
+
+def test_layernorm_chain_step_matches_torch():
+    """NPF_OP_LAYERNORM / NPF_OP_LAYERNORM_BWD against torch.nn.functional.layer_norm (float64):
+    output, input gradient, gamma / beta gradients; feature counts that are not multiples of 32."""
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd.chain import Chain
+
+    g = torch.Generator().manual_seed(12)
+    for n_tasks, pts, F in ((3, 45, 64), (2, 33, 100), (1, 70, 256), (2, 5, 24)):
+        x = (torch.randn(n_tasks, pts, F, generator=g) * 2 + 0.5).requires_grad_(True)
+        gam = (torch.rand(F, generator=g) + 0.5).requires_grad_(True)
+        bet = (torch.randn(F, generator=g) * 0.1).requires_grad_(True)
+        w = torch.randn(n_tasks, pts, F, generator=g)
+        ref = torch.nn.functional.layer_norm(x.double(), (F,), gam.double(), bet.double(), 1e-5)
+        gx, gg, gb = torch.autograd.grad((ref * w.double()).sum(), (x, gam, bet))
+        xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, gam, bet))
+        ch = Chain(n_tasks, pts, DEV)
+        ch.input_pt(FN.pack_pt(xd), F).layernorm(gd, bd, 1e-5).output_pt()
+        y = FN.unpack_pt(ch.run()[0], pts, F)
+        (y * w.to(DEV)).sum().backward()
+        assert_close(y, ref, what=f"layernorm F={F}")
+        assert_close(xd.grad, gx, tol=2e-5, what=f"layernorm dx F={F}")
+        assert_close(gd.grad, gg, tol=2e-5, what=f"layernorm dgamma F={F}")
+        assert_close(bd.grad, gb, tol=2e-5, what=f"layernorm dbeta F={F}")
+
+
+def test_split_merge_heads_roundtrip():
+    """npf_split_heads / npf_merge_heads against the reference's view/permute formulation
+    (attention.py:505-527)."""
+    from npf_gwwaveform_amd import functional as FN
+
+    g = torch.Generator().manual_seed(13)
+    for B, P, F, H in ((3, 40, 128, 8), (2, 33, 64, 8), (1, 70, 256, 8), (2, 9, 96, 4)):
+        x = torch.randn(B, P, F, generator=g)
+        hs = F // H
+        ref = x.view(B, P, H, hs).permute(2, 0, 1, 3).contiguous().view(B * H, P, hs)
+        xd = x.to(DEV)
+        sp = FN.split_heads(FN.pack_pt(xd), B, P, F, H)
+        assert torch.equal(FN.unpack_pt(sp, P, hs).cpu(), ref)
+        back = FN.merge_heads(sp, B, P, F, H)
+        assert torch.equal(FN.unpack_pt(back, P, F).cpu(), x)

@@ -132,7 +132,11 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(ValueError, match="Unknown encoded_path"):
         A.LNP(1, 1, encoded_path="deterministic")
     with pytest.raises(NotImplementedError):
-        A.AttnCNP(1, 1, attention="transformer")
+        A.AttnCNP(1, 1, attention="additive")
+    with pytest.raises(ValueError, match="Unknown attention"):
+        A.AttnCNP(1, 1, attention="nope")
+    with pytest.raises(NotImplementedError):
+        A.AttnCNP(1, 1, attention="transformer", attention_kwargs=dict(dropout=0.1))
     with pytest.raises(NotImplementedError):
         A.AttnCNP(1, 1, is_self_attn=True)
     with pytest.raises(NotImplementedError):
@@ -198,3 +202,25 @@ def test_synthetic_batch_contract():
     assert torch.isfinite(b["Y_cntxt"]).all() and torch.isfinite(b["Y_trgt"]).all()
     b2 = synthetic_waveform_batch(4, 16, 48, 7, "cpu")
     assert torch.equal(b["Y_trgt"], b2["Y_trgt"])
+
+
+def test_transformer_attention_state_dict_matches_shipped_checkpoints():
+    """The shipped Attn* checkpoints' attender keys (results/pretrained/*/AttnCNP/run_0/params.pt:
+    key/query/value transforms, two LayerNorms, the residual MLP) load with strict=True."""
+    import warnings
+
+    import npf_gwwaveform_amd as A
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = A.AttnCNP(1, 1, r_dim=128, attention="transformer")
+    keys = {k for k in m.state_dict() if k.startswith("attender.")}
+    assert keys == {"attender.key_transform.weight", "attender.query_transform.weight", "attender.query_transform.bias",
+                    "attender.value_transform.weight", "attender.layer_norm1.weight", "attender.layer_norm1.bias",
+                    "attender.layer_norm2.weight", "attender.layer_norm2.bias", "attender.mlp.to_hidden.weight",
+                    "attender.mlp.to_hidden.bias", "attender.mlp.out.weight", "attender.mlp.out.bias"}
+    assert m.attender.n_heads == 8 and m.attender.kq_head_size == 16
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mh = A.AttnCNP(1, 1, r_dim=64, attention="multihead")
+    assert "attender.post_processor.weight" in mh.state_dict()
