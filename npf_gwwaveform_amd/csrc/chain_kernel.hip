@@ -511,7 +511,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define NPF_STAMP(i)
 #endif
 
-template <int MAXB, int WAVES>
+// EXTRA: the instance that also carries the rarely used LayerNorm ops (transformer attention).  They
+// are kept out of the main instances on purpose: their per-feature index values are loop-invariant,
+// hipcc hoists them out of the op loop and the main kernel then spills hundreds of registers.
+template <int MAXB, int WAVES, bool EXTRA>
 __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) void chain_kernel(const npf_program_t g) {
   constexpr int kMaxB16 = MAXB;
   constexpr int kSlabFloats = slab_floats(MAXB);
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       for (int b = 0; b < kMaxB16; ++b)
         if (b < FB) cur[b] *= inv;
     } else if (opc == NPF_OP_LAYERNORM || opc == NPF_OP_LAYERNORM_BWD) {
-      if constexpr (MAXB == 16) {
+      if constexpr (EXTRA) {
         // nn.LayerNorm over the F valid features of the point (biased variance, eps inside the root).
         // Forward: cur = x.  Backward: cur = dy, x reloaded from the saved forward input.
         const int F = o.i0, FB = ((F + 31) >> 5) * 2;
@@ -1024,12 +1027,17 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
   const bool paired = !wide && g.reserved[1] == 2;
   const long grid = grid_for(paired ? 4 : 2);
   if (grid <= 0 || grid > 0x7fffffffL) return NPF_EINVAL;
-  if (wide)
-    hipLaunchKernelGGL((npf::chain_kernel<32, 4>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
+  bool extra = false;
+  for (int i = 0; i < g.n_ops; ++i) extra |= g.ops[i].op == NPF_OP_LAYERNORM || g.ops[i].op == NPF_OP_LAYERNORM_BWD;
+  if (extra && wide) return NPF_EINVAL;
+  if (extra)
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, true>), dim3((unsigned)grid_for(2)), dim3(256), 0, (hipStream_t)stream, g);
+  else if (wide)
+    hipLaunchKernelGGL((npf::chain_kernel<32, 4, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
   else if (paired)
-    hipLaunchKernelGGL((npf::chain_kernel<16, 8>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 8, false>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, g);
   else
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }
