@@ -387,11 +387,12 @@ __device__ __forceinline__ void slab_mfma_any(const float* slot, int KB16, const
 // slot per MFMA (~25 cycles per VALU/LDS instruction, ~85 per VMEM instruction;
 // tools/issue_probe.hip).  So the slab DMA, the addend loads and the previous slab's epilogue
 // all ride inside this loop.
-template <int MAXB, class Side>
+template <int KB16S, int MAXB, class Side>
 __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w, const f32x4 (&cur)[MAXB], f32x4& acc0,
                                                f32x4& acc1, Side side) {
-  constexpr int Kp = 256;
-  const int ps = w.p & 15;
+  constexpr int Kp = 16 * KB16S;
+  constexpr int swz = ((Kp >> 2) & 15) ? 7 : 15;
+  const int ps = w.p & swz;
   const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(slot + w.p * Kp);
   unsigned addr[4];
 #pragma unroll
@@ -406,11 +407,11 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
                : "=&v"(nxtf[0]), "=&v"(nxtf[1]), "+v"(curf[0]), "+v"(curf[1])                            \
                : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256), "n"(((kbn) >> 2) * 256 + kRowBlk));
 #pragma unroll
-  for (int kb = 0; kb < 16; ++kb) {
-    if (kb + 1 < 16) {
+  for (int kb = 0; kb < KB16S; ++kb) {
+    if (kb + 1 < KB16S) {
       if ((kb & 1) == 0) { NPF_STEP2(fr[0], fr[1], kb + 1) } else { NPF_STEP2(fr[1], fr[0], kb + 1) }
     } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[1][0]), "+v"(fr[1][1]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[(KB16S - 1) & 1][0]), "+v"(fr[(KB16S - 1) & 1][1]));
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -423,19 +424,26 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 #undef NPF_STEP2
 }
 
-// One 256 -> 256 layer on the fast path, software-pipelined over its 8 slabs.  Stage I:
+// One K -> N layer on the fast path (K = 16 KB16S in {32, 64, 128, 256} inputs, N = 32 NB outputs, full
+// slabs), software-pipelined over its NB slabs.  Stage I:
 //   MFMA loop of slab I accumulating into out[2I], out[2I+1] (initialised with the biases), with
-//   inside it   blocks 0-3 : epilogue of slab I-1, in place (addend / relu / relu-backward mask)
-//               block  4   : addend loads of slab I (HBM; consumed in stage I+1)
-//               blocks 5-12: the 8 DMA pieces of slab I+1 (one SALU add + one instruction each)
-//               block 13   : the bias piece of slab I+1
+//   inside it, in this order over the loop's KB16S blocks:
+//     the epilogue of slab I-1, in place (addend / relu / relu-backward mask), over the first E blocks
+//     the addend loads of slab I (HBM; consumed in stage I+1)
+//     the K/32 DMA pieces of slab I+1 (one SALU add + one instruction each), one per block
+//     the bias piece of slab I+1
 //   barrier (slab I consumed by the workgroup, slab I+1 landed).
 // EPI: 0 = out + addend, 1 = relu(out + addend), 2 = addend > 0 ? out : 0.
-template <int EPI, int MAXB, bool PAIRED, class NextLayer>
-__device__ __forceinline__ void fast_layer_256(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
-                                               f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
-                                               const float* addt, int astep, NextLayer next_layer) {
+template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, class NextLayer>
+__device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
+                                           f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
+                                           const float* addt, int astep, NextLayer next_layer) {
   constexpr int kSlabFloats = slab_floats(MAXB);
+  constexpr int Kp = 16 * KB16S;
+  constexpr int NPW = Kp / 32;                                  // DMA pieces per wave per slab
+  constexpr int E = KB16S >= 8 ? 4 : (KB16S >= 4 ? 2 : 1);      // blocks that carry the previous epilogue
+  constexpr int PPB = 4 / E;                                    // epilogue parts per block
+  static_assert(2 * NB <= MAXB && KB16S <= MAXB, "layer does not fit the register file");
   f32x4 ad[2] = {};
   auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
     const int j = part >> 1, e0 = (part & 1) * 2;
@@ -450,39 +458,43 @@ __device__ __forceinline__ void fast_layer_256(const Wave& w, float* smem, int& 
   };
   const char* wbase = (const char*)op.W;
 #pragma unroll
-  for (int I = 0; I < 8; ++I) {
+  for (int I = 0; I < NB; ++I) {
     const int nxt = PAIRED ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
     float* nslot = smem + nxt * kSlabFloats;
     const float* sl = smem + slot * kSlabFloats;
-    if (I == 7 && issuer) next_layer(nslot);  // slab 0 of the next LINEAR (generic DMA): `op` changes here
+    if (I == NB - 1 && issuer) next_layer(nslot);  // slab 0 of the next LINEAR (generic DMA): `op` changes here
     if (PAIRED && grp_b) __syncthreads();
-    const float* bias = sl + kSlabRows * 256 + 4 * w.g;
+    const float* bias = sl + kSlabRows * Kp + 4 * w.g;
     out[2 * I] = *(const f32x4*)bias;
     out[2 * I + 1] = *(const f32x4*)(bias + 16);
     const char* src = wbase + (size_t)(I + 1) * op.slab_stride * 4;
     const char* bsrc = op.bias != nullptr ? (const char*)(op.bias + (I + 1) * kSlabRows) : (const char*)g_zero128;
-    slab_mfma_side<MAXB>(sl, w, cur, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
-      if (I > 0 && kb < 4) epi_part(I - 1, kb);
-      if (kb == 4) {  // (HBM latency: these must be long gone before the barrier drains vmcnt)
+    slab_mfma_side<KB16S, MAXB>(sl, w, cur, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+      if (I > 0 && kb < E) {
+#pragma unroll
+        for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
+      }
+      if (kb == E) {  // (HBM latency: these must be long gone before the barrier drains vmcnt)
         ad[0] = *(const f32x4*)(addt + (8 * I + w.g) * astep);
         ad[1] = *(const f32x4*)(addt + (8 * I + 4 + w.g) * astep);
       }
-      if (I < 7 && (!PAIRED || issuer)) {
-        if (kb >= 5 && kb < 13) {
-          const int i = kb - 5;
-          dma16_so(src + (size_t)(i * op.step) * 4, op.lo[i], nslot + w.wave * 256 + i * (kWaves * 256));
-        }
+      if (I < NB - 1 && (!PAIRED || issuer)) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (kb == (E + 1 + i < KB16S - 1 ? E + 1 + i : KB16S - 1))
+            dma16_so(src + (size_t)(i * op.step) * 4, op.lo[i], nslot + w.wave * 256 + i * (kWaves * 256));
         // (every issuing wave writes the same 32 biases: no wave-dependent branch in this loop)
-        if (kb == 13) dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, nslot + kSlabRows * 256);
+        if (kb == (E + 1 + NPW < KB16S - 1 ? E + 1 + NPW : KB16S - 1))
+          dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, nslot + kSlabRows * Kp);
       }
     });
     if (!PAIRED || !grp_b) __syncthreads();
     slot = nxt;
   }
 #pragma unroll
-  for (int part = 0; part < 4; ++part) epi_part(7, part);
+  for (int part = 0; part < 4; ++part) epi_part(NB - 1, part);
 #pragma unroll
-  for (int b = 0; b < MAXB; ++b) cur[b] = out[b];
+  for (int b = 0; b < 2 * NB; ++b) cur[b] = out[b];
 }
 
 // reductions over the 4 lane groups that share a point
@@ -514,7 +526,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 // EXTRA: the instance that also carries the rarely used LayerNorm ops (transformer attention).  They
 // are kept out of the main instances on purpose: their per-feature index values are loop-invariant,
 // hipcc hoists them out of the op loop and the main kernel then spills hundreds of registers.
-template <int MAXB, int WAVES, bool EXTRA>
+// FKB, FNB: the one layer shape (K = 16 FKB, N = 32 FNB) this instance runs software-pipelined
+// (0: none).  One shape per instance: two pipelined shapes in one kernel make hipcc spill inside the
+// MFMA loops; the launcher picks the instance by the program's most frequent square layer.
+template <int MAXB, int WAVES, bool EXTRA, int FKB, int FNB>
 __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) void chain_kernel(const npf_program_t g) {
   constexpr int kMaxB16 = MAXB;
   constexpr int kSlabFloats = slab_floats(MAXB);
@@ -622,15 +637,16 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       // cursor logic runs once per layer.  While the sibling wave of the SIMD is inside its
       // MFMA loop every VALU instruction of this wave waits for an fp32 MFMA to drain (~32
       // cycles), so what counts outside the MFMA loop is the number of VALU instructions.
-      bool fast_layer = false;
-      if constexpr (MAXB == 16)
-        fast_layer = KB16 == 16 && N == 256 && g.reserved[0] == 0 && (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast));
-      if (fast_layer) {
-        if constexpr (MAXB == 16) {
-          // this layer's slabs 1..7 stream inside the pipeline; then the cursor jumps to the next
+      bool fast_shape = false;
+      if constexpr (FKB > 0)
+        fast_shape = KB16 == FKB && N == 32 * FNB && o.i0 == 16 * FKB && g.reserved[0] == 0 &&
+                     (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast));
+      if (fast_shape) {
+        if constexpr (FKB > 0) {
+          // this layer's slabs 1.. stream inside the pipeline; then the cursor jumps to the next
           // LINEAR and its slab 0 goes out through the generic DMA code before the last stage
           auto next_layer = [&](float* nslot) __attribute__((always_inline)) {
-            pf.nb = 7;
+            pf.nb = FNB - 1;
             advance();
             if (pf.op < g.n_ops) {
               SlabDma d = dma_begin(pfs, pf.nb, w, nslot, true);
@@ -638,9 +654,9 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
               advance();
             }
           };
-          if (mask) fast_layer_256<2, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
-          else if (relu) fast_layer_256<1, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
-          else fast_layer_256<0, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          if (mask) fast_layer<2, FKB, FNB, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else if (relu) fast_layer<1, FKB, FNB, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else fast_layer<0, FKB, FNB, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
         }
       } else {
       // Generic path: runtime slab loop with *static* register indices: finished blocks enter a register
@@ -1028,16 +1044,28 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
   const long grid = grid_for(paired ? 4 : 2);
   if (grid <= 0 || grid > 0x7fffffffL) return NPF_EINVAL;
   bool extra = false;
-  for (int i = 0; i < g.n_ops; ++i) extra |= g.ops[i].op == NPF_OP_LAYERNORM || g.ops[i].op == NPF_OP_LAYERNORM_BWD;
+  int n256 = 0, n128 = 0;
+  for (int i = 0; i < g.n_ops; ++i) {
+    const npf_op_t& o = g.ops[i];
+    extra |= o.op == NPF_OP_LAYERNORM || o.op == NPF_OP_LAYERNORM_BWD;
+    if (o.op == NPF_OP_LINEAR) {
+      n256 += o.i0 == 256 && o.i1 == 256;
+      n128 += o.i0 == 128 && o.i1 == 128;
+    }
+  }
   if (extra && wide) return NPF_EINVAL;
+  const dim3 b4(256), b8(512);
+  const hipStream_t st = (hipStream_t)stream;
   if (extra)
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4, true>), dim3((unsigned)grid_for(2)), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, true, 0, 0>), dim3((unsigned)grid_for(2)), b4, 0, st, g);
   else if (wide)
-    hipLaunchKernelGGL((npf::chain_kernel<32, 4, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<32, 4, false, 0, 0>), dim3((unsigned)grid), b4, 0, st, g);
   else if (paired)
-    hipLaunchKernelGGL((npf::chain_kernel<16, 8, false>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 8, false, 16, 8>), dim3((unsigned)grid), b8, 0, st, g);
+  else if (n128 > n256)
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 8, 4>), dim3((unsigned)grid), b4, 0, st, g);
   else
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 16, 8>), dim3((unsigned)grid), b4, 0, st, g);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

@@ -224,3 +224,30 @@ def test_transformer_attention_state_dict_matches_shipped_checkpoints():
         warnings.simplefilter("ignore")
         mh = A.AttnCNP(1, 1, r_dim=64, attention="multihead")
     assert "attender.post_processor.weight" in mh.state_dict()
+
+
+def test_hot_kernel_instances_do_not_spill():
+    """A source change that makes hipcc spill inside the MFMA loops fails no parity test -- it only shows
+    up as a slowdown -- so the register budget of the hot instances is pinned here (compile to
+    assembly, read the kernel descriptors): main chain instance and wgrad kernel."""
+    import subprocess
+    import tempfile
+
+    from npf_gwwaveform_amd import _build
+
+    with tempfile.TemporaryDirectory() as tmp:
+        spills = {}
+        for src in ("chain_kernel.hip", "wgrad_kernel.hip"):
+            out = os.path.join(tmp, src + ".s")
+            subprocess.run([_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                            "-I", _build.CSRC, "--cuda-device-only", "-S", os.path.join(_build.CSRC, src), "-o", out],
+                           check=True, stderr=subprocess.DEVNULL)
+            txt = open(out).read()
+            names = re.findall(r"^\s+\.name:\s+(\S+)", txt, flags=re.M)
+            counts = re.findall(r"^\s+\.vgpr_spill_count:\s+(\d+)", txt, flags=re.M)
+            spills.update(dict(zip(names, map(int, counts))))
+    main = [k for k in spills if "chain_kernelILi16ELi4ELb0ELi16ELi8" in k]
+    assert len(main) == 1, spills
+    assert spills[main[0]] <= 32, f"main chain_kernel instance spills {spills[main[0]]} VGPRs"
+    wg = [k for k in spills if "wgrad_kernelE" in k]
+    assert len(wg) == 1 and spills[wg[0]] == 0, spills
