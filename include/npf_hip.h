@@ -20,6 +20,7 @@
  *   npf_mean_agg_fwd/bwd torch.mean(R_cntxt, dim=1)       npf/neuralproc/np.py:95, attnnp.py:181
  *   npf_pack_pt/unpack_pt  layout change at the module boundary (no reference counterpart)
  *   npf_transpose        W -> W^T for the dgrad chains (no reference counterpart)
+ *   npf_gather_points    CntxtTrgtGetter.select              npf/utils/datasplit.py:246-255
  *   npf_split_heads/npf_merge_heads  MultiheadAttender._make_multiheaded / _concatenate_multiheads
  *                                                         npf/architectures/attention.py:505-527
  *
@@ -194,6 +195,12 @@ int npf_split_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int
                     void *stream);
 int npf_merge_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int32_t F, int32_t n_heads, float *dst,
                     void *stream);
+
+/* Context / target selection (CntxtTrgtGetter.select, npf/utils/datasplit.py:246-255: torch.gather along
+ * the points of X and y with the same indices): out_x[b][i][:] = x[b][idx[b][i]][:], same for y.
+ * idx: int64 [n_tasks][n_sel], every entry in [0, n_points) (checked on the host side). */
+int npf_gather_points(const float *x, const float *y, const int64_t *idx, int32_t n_tasks, int32_t n_points,
+                      int32_t n_sel, int32_t x_dim, int32_t y_dim, float *out_x, float *out_y, void *stream);
 
 /* Library / device info. */
 int npf_version(void);

@@ -6,6 +6,7 @@ The compute runs in hand-written HIP kernels (``csrc/``) reached through a C ABI
 """
 from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, TransformerAttender, get_attender,
                             merge_flat_input)
+from .datasplit import CntxtTrgtGetter, GetRandomIndcs, GetRangeIndcs, get_all_indcs
 from .losses import CNPFLoss, ELBOLossLNPF, NLLLossLNPF
 from .neuralproc import (CNP, LNP, AttnCNP, AttnLNP, LatentNeuralProcessFamily, MultivariateNormalDiag,
                          NeuralProcessFamily)
@@ -35,4 +36,5 @@ __all__ = [
     "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "get_attender",
     "NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP", "NPFModel",
     "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "MultivariateNormalDiag", "encode", "aggregate", "decode",
+    "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs",
 ]

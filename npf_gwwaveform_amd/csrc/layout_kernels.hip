@@ -89,6 +89,24 @@ __global__ void heads_kernel(const float* __restrict__ src, int n_tasks, int pts
   }
 }
 
+// CntxtTrgtGetter.select: one thread per selected (task, point); x_dim and y_dim are tiny (1-3 floats).
+__global__ void gather_points_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                     const long long* __restrict__ idx, int n_tasks, int n_points, int n_sel, int x_dim,
+                                     int y_dim, float* __restrict__ out_x, float* __restrict__ out_y) {
+  const size_t total = (size_t)n_tasks * n_sel;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = t / n_sel;
+    long long j = idx[t];
+    j = j < 0 ? 0 : (j >= n_points ? n_points - 1 : j);  // (the host validates; never read out of bounds)
+    const float* xs = x + (b * n_points + (size_t)j) * x_dim;
+    for (int d = 0; d < x_dim; ++d) out_x[t * x_dim + d] = xs[d];
+    if (y) {
+      const float* ys = y + (b * n_points + (size_t)j) * y_dim;
+      for (int d = 0; d < y_dim; ++d) out_y[t * y_dim + d] = ys[d];
+    }
+  }
+}
+
 // 32x32 LDS tile transpose
 __global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
   __shared__ float tile[32][33];
@@ -190,6 +208,18 @@ static int heads_launch(bool split, const float* src, int32_t n_tasks, int32_t p
     hipLaunchKernelGGL(npf::heads_kernel<false>, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
                        n_tasks, pts, Fp, hsz, n_heads, dst);
   }
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_gather_points(const float* x, const float* y, const int64_t* idx, int32_t n_tasks, int32_t n_points,
+                                 int32_t n_sel, int32_t x_dim, int32_t y_dim, float* out_x, float* out_y, void* stream) {
+  if (!x || !idx || !out_x || n_tasks <= 0 || n_points <= 0 || n_sel < 0 || x_dim <= 0) return NPF_EINVAL;
+  if (y && (!out_y || y_dim <= 0)) return NPF_EINVAL;
+  if (n_sel == 0) return NPF_OK;
+  const size_t total = (size_t)n_tasks * n_sel;
+  hipLaunchKernelGGL(npf::gather_points_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     (const long long*)idx, n_tasks, n_points, n_sel, x_dim, y_dim, out_x, out_y);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

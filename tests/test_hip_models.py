@@ -315,3 +315,35 @@ def test_pretrained_attn_checkpoints_match_reference():
             ref_err = np.abs(ref32 - exact).max()
             err = np.abs(got.cpu().double().numpy() - exact).max()
             assert err <= 2.0 * ref_err + 1e-5 * m, f"{tag} {key}: |hip - fp64| = {err:.3e}, |reference fp32 - fp64| = {ref_err:.3e}"
+
+
+def test_context_target_getter_matches_reference_selection():
+    """CntxtTrgtGetter (npf/utils/datasplit.py:148-255): with explicit indices the selection equals
+    the reference's torch.gather formulation bit for bit; drawn indices give a valid split that the
+    model trains on; is_add_cntxts_to_trgts appends the context indices."""
+    import npf_gwwaveform_amd as A
+
+    g = torch.Generator().manual_seed(21)
+    B, N, dx, dy = 5, 64, 2, 3
+    X, Y = torch.rand(B, N, dx, generator=g) * 2 - 1, torch.randn(B, N, dy, generator=g)
+    ci = torch.stack([torch.randperm(N, generator=g)[:17] for _ in range(B)])
+    ti = torch.arange(N).expand(B, N)
+    getter = A.CntxtTrgtGetter()
+    Xc, Yc, Xt, Yt = getter(X.to(DEV), Y.to(DEV), context_indcs=ci, target_indcs=ti)
+    ref = lambda t, i: torch.gather(t, 1, i.unsqueeze(-1).expand(B, -1, t.shape[-1]))  # noqa: E731
+    assert torch.equal(Xc.cpu(), ref(X, ci)) and torch.equal(Yc.cpu(), ref(Y, ci))
+    assert torch.equal(Xt.cpu(), X) and torch.equal(Yt.cpu(), Y)
+    with pytest.raises(IndexError):
+        getter(X.to(DEV), Y.to(DEV), context_indcs=ci + N, target_indcs=ti)
+    add = A.CntxtTrgtGetter(contexts_getter=A.GetRandomIndcs(a=4, b=4), targets_getter=A.GetRandomIndcs(a=10, b=10),
+                            is_add_cntxts_to_trgts=True)
+    Xc, Yc, Xt, Yt = add(X.to(DEV), Y.to(DEV))
+    assert Xc.shape == (B, 4, dx) and Xt.shape == (B, 14, dx) and torch.equal(Xt[:, 10:], Xc) and torch.equal(Yt[:, 10:], Yc)
+    # a drawn split feeds the model
+    case = dict(specs.CASES["g6_cnp_homosk"])
+    model = build_model(case, DEV).train()
+    Xc, Yc, Xt, Yt = A.CntxtTrgtGetter()(X.to(DEV), Y.to(DEV))
+    assert 6 <= Xc.shape[1] <= 32 and Xt.shape[1] == N
+    loss = A.CNPFLoss()(model(Xc, Yc, Xt, Yt), Yt)
+    loss.backward()
+    assert torch.isfinite(loss)

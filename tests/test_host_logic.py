@@ -251,3 +251,28 @@ def test_hot_kernel_instances_do_not_spill():
     assert spills[main[0]] <= 32, f"main chain_kernel instance spills {spills[main[0]]} VGPRs"
     wg = [k for k in spills if "wgrad_kernelE" in k]
     assert len(wg) == 1 and spills[wg[0]] == 0, spills
+
+
+def test_index_getters_follow_reference_contract():
+    """GetRandomIndcs / GetRangeIndcs / get_all_indcs (npf/utils/datasplit.py:30-145): shapes, ranges,
+    per-row subsets without repetition, shared rows with is_batch_share (CPU tensors: no kernel)."""
+    import npf_gwwaveform_amd as A
+
+    assert A.get_all_indcs(3, 7).shape == (3, 7)
+    assert torch.equal(A.GetRangeIndcs((2, 6))(4, 100), torch.arange(2, 6).expand(4, 4))
+    g = A.GetRandomIndcs(a=0.25, b=0.5)
+    for _ in range(5):
+        idx = g(6, 40)
+        assert idx.shape[0] == 6 and 10 <= idx.shape[1] <= 20
+        assert int(idx.min()) >= 0 and int(idx.max()) < 40
+        assert all(len(set(r.tolist())) == idx.shape[1] for r in idx)
+    assert not torch.equal(idx[0].sort().values, idx[1].sort().values) or idx.shape[1] == 40
+    shared = A.GetRandomIndcs(a=5, b=5, is_batch_share=True)(4, 30)
+    assert shared.shape == (4, 5) and all(torch.equal(shared[0], r) for r in shared)
+    ranged = A.GetRandomIndcs(a=3, b=3, range_indcs=(10, 20))(2, 100)
+    assert ranged.shape == (2, 3) and int(ranged.min()) >= 10 and int(ranged.max()) < 20
+    assert A.GetRandomIndcs(a=0, b=0, is_ensure_one=True)(2, 10).shape == (2, 1)
+    with pytest.raises(ValueError):
+        A.GetRandomIndcs(a=-1, b=2)(2, 10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        A.CntxtTrgtGetter()(torch.zeros(2, 10, 1), torch.zeros(2, 10, 2))
