@@ -7,7 +7,7 @@ The compute runs in hand-written HIP kernels (``csrc/``) reached through a C ABI
 from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, TransformerAttender, get_attender,
                             merge_flat_input)
 from .datasplit import CntxtTrgtGetter, GetRandomIndcs, GetRangeIndcs, get_all_indcs
-from .losses import CNPFLoss, ELBOLossLNPF, NLLLossLNPF
+from .losses import CNPFLoss, ELBOLossLNPF, LightTailPareto, NLLLossLNPF, SUMOLossLNPF
 from .neuralproc import (CNP, LNP, AttnCNP, AttnLNP, LatentNeuralProcessFamily, MultivariateNormalDiag,
                          NeuralProcessFamily)
 
@@ -35,6 +35,6 @@ def decode(model: NeuralProcessFamily, X_trgt_enc, R_trgt):
 __all__ = [
     "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "get_attender",
     "NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP", "NPFModel",
-    "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "MultivariateNormalDiag", "encode", "aggregate", "decode",
+    "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "SUMOLossLNPF", "LightTailPareto", "MultivariateNormalDiag", "encode", "aggregate", "decode",
     "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs",
 ]

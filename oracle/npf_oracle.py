@@ -343,6 +343,26 @@ def nll_loss(out: dict, Y_trgt: torch.Tensor, reduction: Optional[str] = "mean")
     return _reduce(-(torch.logsumexp(s, 0) - math.log(n_z)), reduction)
 
 
+def sumo_loss(out: dict, Y_trgt: torch.Tensor, reduction: Optional[str] = "mean", a: int = 5, alpha: int = 85):
+    """``SUMOLossLNPF`` (npf/losses.py:207-276) with the default number-of-samples distribution
+    ``LightTailPareto(a=5).freeze(85)`` (npf/utils/helpers.py:36-53: P(K >= k) = 1/(k - a) below
+    ``alpha - a``, geometric beyond).  ``logcumsumexp`` is the reference's running logsumexp
+    (helpers.py:20-33)."""
+    s = sum_log_prob(out["loc"], out["scale"], Y_trgt)
+    n_z = s.shape[0]
+    if out["q_zCct"] is not None:
+        z = out["z_samples"]
+        s = s + sum_log_prob(*out["q_zCc"], z) - sum_log_prob(*out["q_zCct"], z)
+    ks = torch.arange(1, n_z + 1).unsqueeze(-1)
+    cum_iwae = torch.cat([torch.logsumexp(s[:i], dim=0, keepdim=True) for i in range(1, n_z + 1)], dim=0) - ks.float().log()
+    kk = (ks - 1 + 1 - a).clamp(min=1).double()            # cdf(ks - 1): k -> k + 1 - m, clipped at 1
+    al = float(alpha - a)
+    tail = torch.where(kk < al, 1.0 / kk, (1.0 / al) * 0.9 ** (kk - al))
+    inv_weights = tail                                      # 1 - cdf = P(K >= k)
+    sumo = cum_iwae[a - 1] + (inv_weights[a:] * (cum_iwae[a:] - cum_iwae[a - 1:-1])).sum(0)
+    return _reduce(-sumo, reduction)
+
+
 def _reduce(loss, reduction):
     if reduction is None:
         return loss

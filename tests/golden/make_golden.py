@@ -80,7 +80,8 @@ def build_reference(case: dict):
 
 
 def ref_loss(case: dict):
-    return {"cnpf": npf.CNPFLoss, "elbo": npf.ELBOLossLNPF, "nll": npf.NLLLossLNPF}[specs.loss_name(case)]()
+    return {"cnpf": npf.CNPFLoss, "elbo": npf.ELBOLossLNPF, "nll": npf.NLLLossLNPF,
+            "sumo": npf.SUMOLossLNPF}[specs.loss_name(case)]()
 
 
 def run_case(name: str, case: dict, store_params: bool, store_full_grads: bool, adam_step: bool = False):

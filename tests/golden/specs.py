@@ -52,6 +52,11 @@ CASES = {
     "g8_attncnp_multihead": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=45, attention="multihead"),
     "g8_attncnp_transformer": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=45,
                                    attention="transformer"),
+    # G10: multi-sample objectives -- SUMO with importance weights, 8 latent samples
+    "g10_lnp_sumo": dict(kind="LNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=4, C=10, T=24, encoded_path="latent",
+                         is_q_zCct=True, n_z=8, loss="sumo"),
+    "g10_attnlnp_nll_nz8": dict(kind="AttnLNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=12, T=20, is_q_zCct=True, n_z=8,
+                                loss="nll"),
     "g8_attnlnp_transformer": dict(kind="AttnLNP", r=128, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=33, T=40,
                                    attention="transformer", is_q_zCct=True, n_z=2),
 }
@@ -114,6 +119,8 @@ def load_golden(name: str) -> dict:
 
 
 def loss_name(case: dict) -> str:
+    if "loss" in case:
+        return case["loss"]
     if case["kind"] in ("CNP", "AttnCNP"):
         return "cnpf"
     return "elbo" if case.get("is_q_zCct", False) else "nll"

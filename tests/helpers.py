@@ -54,7 +54,8 @@ def build_model(case: dict, device="cuda:0", params=None):
 def build_loss(case: dict):
     import npf_gwwaveform_amd as A
 
-    return {"cnpf": A.CNPFLoss, "elbo": A.ELBOLossLNPF, "nll": A.NLLLossLNPF}[specs.loss_name(case)]()
+    return {"cnpf": A.CNPFLoss, "elbo": A.ELBOLossLNPF, "nll": A.NLLLossLNPF,
+            "sumo": A.SUMOLossLNPF}[specs.loss_name(case)]()
 
 
 def assert_close(got, ref, tol=1e-5, what=""):

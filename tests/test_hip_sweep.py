@@ -13,7 +13,7 @@ from oracle import npf_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-LOSSES = {"cnpf": O.cnpf_loss, "elbo": O.elbo_loss, "nll": O.nll_loss}
+LOSSES = {"cnpf": O.cnpf_loss, "elbo": O.elbo_loss, "nll": O.nll_loss, "sumo": O.sumo_loss}
 
 SWEEP = {
     "cnp_r48": dict(kind="CNP", r=48, L_xy=2, L_dec=3, dx=1, dy=2, B=5, C=17, T=45),

@@ -12,7 +12,7 @@ torch.set_num_threads(8)
 
 SMALL = [n for n, c in specs.CASES.items() if c["r"] < 256]
 BIG = [n for n, c in specs.CASES.items() if c["r"] >= 256]
-LOSSES = {"cnpf": O.cnpf_loss, "elbo": O.elbo_loss, "nll": O.nll_loss}
+LOSSES = {"cnpf": O.cnpf_loss, "elbo": O.elbo_loss, "nll": O.nll_loss, "sumo": O.sumo_loss}
 
 
 def run_oracle(case, training=True, with_grad=True):
