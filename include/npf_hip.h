@@ -77,7 +77,8 @@ enum npf_opcode {
                               weights W[n = feature][k = point] (s0 = i0*i1, i3 = i1)            */
   NPF_OP_LAYERNORM = 15,   /* cur <- (cur - mean) / sqrt(var + f0) * p0[f] + p1[f] over the i0 <= 256
                               features of the point (nn.LayerNorm of TransformerAttender,
-                              npf/architectures/attention.py:552-553,583-586)                    */
+                              npf/architectures/attention.py:552-553,583-586); p0 (gamma), p1
+                              (beta): 16-byte aligned, zero-padded to a multiple of 32 floats    */
   NPF_OP_LAYERNORM_BWD = 16 /* cur = dy on entry; x = PT32 p0 (the forward input, i0 = F), gamma p1:
                               xhat = (x - mean) rstd;  PT32 p2 <- dy * xhat (for dgamma);
                               cur <- rstd (g - mean(g) - xhat mean(g xhat)),  g = dy * gamma      */

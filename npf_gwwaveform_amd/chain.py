@@ -42,6 +42,16 @@ def pt_shape(n_tasks: int, pts: int, F: int):
     return (n_tasks, tiles_of(pts), pad32(F) // 4, 32, 4)
 
 
+def _pad_vec(v: torch.Tensor) -> torch.Tensor:
+    """A per-feature vector zero-padded to a multiple of 32 floats (LayerNorm gamma / beta)."""
+    n = v.shape[0]
+    if n == pad32(n) and v.is_contiguous() and v.data_ptr() % 16 == 0:
+        return v
+    out = torch.zeros(pad32(n), dtype=torch.float32, device=v.device)
+    out[:n] = v
+    return out
+
+
 def pt_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
     return torch.empty(pt_shape(n_tasks, pts, F), dtype=torch.float32, device=device)
 
@@ -425,7 +435,7 @@ class _ChainFn(torch.autograd.Function):
                 upstream = upstream or needs_grad[gi] or needs_grad[bi]
                 if train and upstream:
                     saved[(i, "in")] = ensure_saved(a["F"])
-                prog.layernorm(T[gi].contiguous(), T[bi].contiguous(), a["F"], a["eps"])
+                prog.layernorm(_pad_vec(T[gi]), _pad_vec(T[bi]), a["F"], a["eps"])
                 backed = None
             elif k == "attn_scores":
                 kk = st.t["k"]
@@ -568,7 +578,7 @@ class _ChainFn(torch.autograd.Function):
                 if needs_grad[gi]:
                     dyx = new_pt(a["F"])
                     pending_vec.append((gi, dyx, a["F"]))
-                prog.layernorm_bwd(saved[(i, "in")], T[gi].contiguous(), a["F"], a["eps"], dy_xhat=dyx)
+                prog.layernorm_bwd(saved[(i, "in")], _pad_vec(T[gi]), a["F"], a["eps"], dy_xhat=dyx)
             elif k == "attn_values":
                 vv = st.t["v"]
                 if needs_grad[vv]:

@@ -841,13 +841,16 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       if constexpr (EXTRA) {
         // nn.LayerNorm over the F valid features of the point (biased variance, eps inside the root).
         // Forward: cur = x.  Backward: cur = dy, x reloaded from the saved forward input.
+        // gamma / beta are padded with zeros to a multiple of 32 floats (host side) and the padding
+        // features of x / dy are zero, so no per-feature masks are needed: the padding's share of
+        // the variance sum, (Fp - F) mean^2, is subtracted after the reduction.
         const int F = o.i0, FB = ((F + 31) >> 5) * 2;
-        const float invF = 1.f / (float)F, eps = o.f0;
+        const float invF = 1.f / (float)F, eps = o.f0, npad = (float)(16 * FB - F);
         const bool bwd = opc == NPF_OP_LAYERNORM_BWD;
-        const float* gam = (const float*)o.p1;
-        if (!bwd) gam = (const float*)o.p0;
-        const float* bet = (const float*)o.p1;  // forward only
-        const float* xt = bwd ? pt_lane(o.p0, g, w, ((F + 31) >> 5) * 32, 0) : Z;
+        const float* gam = (const float*)(bwd ? o.p1 : o.p0) + 4 * w.g;
+        const float* bet = (const float*)o.p1 + 4 * w.g;  // forward only
+        const int lim = F - 4 * w.g;                      // feature 16 b + 4 g + e is valid iff 16 b + e < lim
+        const float* xt = bwd ? pt_lane(o.p0, g, w, 16 * FB, 0) : Z;
         f32x4 x[kMaxB16];
         float s1 = 0.f;
 #pragma unroll
@@ -859,61 +862,47 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
             } else {
               x[b] = cur[b];
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (16 * b + 4 * w.g + e < F) s1 += x[b][e];
+            s1 += (x[b][0] + x[b][1]) + (x[b][2] + x[b][3]);
           }
         }
         const float mean = xg_sum(s1) * invF;
         float s2 = 0.f;
 #pragma unroll
         for (int b = 0; b < kMaxB16; ++b)
-          if (b < FB)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool ok = 16 * b + 4 * w.g + e < F;
-              const float d = ok ? x[b][e] - mean : 0.f;
-              x[b][e] = d;
-              s2 += d * d;
-            }
-        const float rstd = 1.f / sqrtf(xg_sum(s2) * invF + eps);
+          if (b < FB) {
+            x[b] = x[b] - mean;
+            s2 += (x[b][0] * x[b][0] + x[b][1] * x[b][1]) + (x[b][2] * x[b][2] + x[b][3] * x[b][3]);
+          }
+        const float var = fmaxf((xg_sum(s2) - npad * mean * mean) * invF, 0.f);
+        const float rstd = 1.f / sqrtf(var + eps);
         if (!bwd) {
 #pragma unroll
           for (int b = 0; b < kMaxB16; ++b)
-            if (b < FB)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int f = 16 * b + 4 * w.g + e;
-                cur[b][e] = f < F ? x[b][e] * rstd * gam[f] + bet[f] : 0.f;
-              }
+            if (b < FB) cur[b] = x[b] * rstd * *(const f32x4*)(gam + 16 * b) + *(const f32x4*)(bet + 16 * b);
         } else {
-          float* xo = o.p2 ? (float*)pt_lane(o.p2, g, w, ((F + 31) >> 5) * 32, 0) : nullptr;
+          float* xo = o.p2 ? (float*)pt_lane(o.p2, g, w, 16 * FB, 0) : nullptr;
           float m1 = 0.f, m2 = 0.f;
 #pragma unroll
           for (int b = 0; b < kMaxB16; ++b)
             if (b < FB) {
-              f32x4 dyx;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int f = 16 * b + 4 * w.g + e;
-                const float xh = x[b][e] * rstd;  // 0 on padding features
-                const float gg = f < F ? cur[b][e] * gam[f] : 0.f;
-                dyx[e] = cur[b][e] * xh;
-                x[b][e] = xh;
-                cur[b][e] = gg;
-                m1 += gg;
-                m2 += gg * xh;
-              }
+              const f32x4 xh = x[b] * rstd;
+              const f32x4 dyx = cur[b] * xh;  // (dy is zero on padding features)
+              const f32x4 gg = cur[b] * *(const f32x4*)(gam + 16 * b);
+              x[b] = xh;
+              cur[b] = gg;
+              m1 += (gg[0] + gg[1]) + (gg[2] + gg[3]);
+              m2 += (gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3]);
               if (xo && w.valid) *(f32x4*)(xo + (4 * b + w.g) * 128) = dyx;
             }
           m1 = xg_sum(m1) * invF;
           m2 = xg_sum(m2) * invF;
 #pragma unroll
           for (int b = 0; b < kMaxB16; ++b)
-            if (b < FB)
+            if (b < FB) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                cur[b][e] = (16 * b + 4 * w.g + e < F) ? rstd * (cur[b][e] - m1 - x[b][e] * m2) : 0.f;
+                cur[b][e] = (16 * b + e < lim) ? rstd * (cur[b][e] - m1 - x[b][e] * m2) : 0.f;
+            }
         }
       }
     } else if (opc == NPF_OP_ADD_TASKVEC) {
@@ -993,11 +982,12 @@ static int validate(const npf_program_t* g) {
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || !o.p0 || o.i1 < g->tiles_per_task * 32) return NPF_EINVAL;
         break;
       case NPF_OP_LAYERNORM:
-        if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 || !(o.f0 > 0.f)) return NPF_EINVAL;
+        if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 || ((((uintptr_t)o.p0) | ((uintptr_t)o.p1)) & 15) || !(o.f0 > 0.f))
+          return NPF_EINVAL;
         break;
       case NPF_OP_LAYERNORM_BWD:
-        if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 || (((uintptr_t)o.p0) & 15) || (((uintptr_t)o.p2) & 15) ||
-            !(o.f0 > 0.f))
+        if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 ||
+            ((((uintptr_t)o.p0) | ((uintptr_t)o.p1) | ((uintptr_t)o.p2)) & 15) || !(o.f0 > 0.f))
           return NPF_EINVAL;
         break;
       case NPF_OP_RELU:
