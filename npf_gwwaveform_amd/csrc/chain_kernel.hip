@@ -482,7 +482,7 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
 #pragma unroll
         for (int i = 0; i < NPW; ++i)
           if (kb == (E + 1 + i < KB16S - 1 ? E + 1 + i : KB16S - 1))
-            dma16_so(src + (size_t)(i * op.step) * 4, op.lo[i], nslot + w.wave * 256 + i * (kWaves * 256));
+            dma16_so(src + (size_t)(i * op.step) * 4, op.lo[i & 7], nslot + w.wave * 256 + i * (kWaves * 256));
         // (every issuing wave writes the same 32 biases: no wave-dependent branch in this loop)
         if (kb == (E + 1 + NPW < KB16S - 1 ? E + 1 + NPW : KB16S - 1))
           dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, nslot + kSlabRows * Kp);
