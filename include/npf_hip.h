@@ -79,6 +79,7 @@ enum npf_opcode {
                               features of the point (nn.LayerNorm of TransformerAttender,
                               npf/architectures/attention.py:552-553,583-586); p0 (gamma), p1
                               (beta): 16-byte aligned, zero-padded to a multiple of 32 floats    */
+  NPF_OP_LOAD_RM = 17,     /* cur <- row-major p0 [task][pt][i0], i0 % 32 == 0, i0 <= 512 (i4 = modulus)  */
   NPF_OP_LAYERNORM_BWD = 16 /* cur = dy on entry; x = PT32 p0 (the forward input, i0 = F), gamma p1:
                               xhat = (x - mean) rstd;  PT32 p2 <- dy * xhat (for dgamma);
                               cur <- rstd (g - mean(g) - xhat mean(g xhat)),  g = dy * gamma      */
@@ -95,6 +96,8 @@ enum npf_wmode {
 #define NPF_F_RELU 1u
 #define NPF_F_ADD_PT 2u /* add PT32 tensor p2 (same F as the output) before the activation     */
 #define NPF_F_MASK_PT 4u /* out = (PT32 tensor p2 > 0) ? out : 0 (fused relu backward); not with ADD_PT */
+#define NPF_F_ADD_RM 8u  /* like ADD_PT with a row-major addend p2 [task][pt][i1] (i1 % 32 == 0): module-
+                            boundary tensors enter without a layout pass (inference paths)            */
 
 typedef struct npf_op {
   int32_t op;        /* npf_opcode                                                              */

@@ -143,12 +143,13 @@ class MergeFlatInputs(nn.Module):
         pass
 
     def append_to(self, ch: Chain, x1_pt: Optional[torch.Tensor] = None, x1_modulus: int = 0,
-                  x1_taskvec: bool = False) -> Chain:
-        """cur = x2 on entry.  ``x1_pt``: PT32 tensor added before the ReLU."""
+                  x1_taskvec: bool = False, x1_rm: bool = False) -> Chain:
+        """cur = x2 on entry.  ``x1_pt``: PT32 tensor added before the ReLU (``x1_rm``: it is a
+        row-major [tasks, pts, x1_dim] tensor instead)."""
         rl = self.resizer.layers()
         for j, lin in enumerate(rl[:-1]):
             ch.linear(lin.weight, lin.bias, relu=True)
-        ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=x1_modulus)
+        ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=x1_modulus, addend_rm=x1_rm)
         return self.flat_module.append_to(ch)
 
     def forward(self, x1, x2):
@@ -166,9 +167,21 @@ class MergeFlatInputs(nn.Module):
         if T == 0 or n2 == 0:
             return x1.new_zeros(*lead2, T, n_out)
         ch = Chain(n2, T, x1.device)
-        ch.input_pt(FN.pack_pt(x2.reshape(n2, T, x2.shape[-1])), x2.shape[-1])
-        self.append_to(ch, FN.pack_pt(x1.reshape(n1, T, d1)), x1_modulus=(n1 if n1 != n2 else 0)).output_pt()
-        (y,) = ch.run()
+        d2 = x2.shape[-1]
+        no_grad = not torch.is_grad_enabled() or not (x1.requires_grad or x2.requires_grad or
+                                                      any(p.requires_grad for p in self.parameters()))
+        if no_grad and d1 % 32 == 0 and d2 % 32 == 0:
+            # inference: the row-major module-boundary tensors go straight into the chain (no PT32
+            # packing pass over x1 and x2)
+            ch.input_rm(x2.reshape(n2, T, d2).contiguous(), d2)
+            self.append_to(ch, x1.reshape(n1, T, d1).contiguous(), x1_modulus=(n1 if n1 != n2 else 0), x1_rm=True)
+        else:
+            ch.input_pt(FN.pack_pt(x2.reshape(n2, T, d2)), d2)
+            self.append_to(ch, FN.pack_pt(x1.reshape(n1, T, d1)), x1_modulus=(n1 if n1 != n2 else 0))
+        if n_out <= 32:
+            (y,) = ch.output_rows().run()
+            return y[..., :n_out].reshape(*lead2, T, n_out)
+        (y,) = ch.output_pt().run()
         return FN.unpack_pt(y, T, n_out).reshape(*lead2, T, n_out)
 
 

@@ -84,6 +84,10 @@ class Program:
     def load_pt(self, t, F, modulus=0):
         self._op(op=L.OP_LOAD_PT, i0=pad32(F), i4=modulus, p0=self._p(t))
 
+    def load_rm(self, t, F, modulus=0):
+        """cur <- row-major [n_tasks (or modulus), pts, F] tensor, F a multiple of 32."""
+        self._op(op=L.OP_LOAD_RM, i0=F, i4=modulus, p0=self._p(t))
+
     def store_pt(self, t, F):
         self._op(op=L.OP_STORE_PT, i0=pad32(F), p0=self._p(t))
 
@@ -131,8 +135,8 @@ class Program:
         self._op(op=L.OP_ADD_TASKVEC, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
 
     def linear(self, W, K, N, bias=None, relu=False, addend=None, addend_modulus=0, mode=L.W_ROWMAJOR, ldw=None,
-               w_tiles=0, w_task_stride=0, b_task_stride=0):
-        flags = (L.F_RELU if relu else 0) | (L.F_ADD_PT if addend is not None else 0)
+               w_tiles=0, w_task_stride=0, b_task_stride=0, addend_rm=False):
+        flags = (L.F_RELU if relu else 0) | ((L.F_ADD_RM if addend_rm else L.F_ADD_PT) if addend is not None else 0)
         i3 = (ldw if ldw is not None else K) if mode == L.W_ROWMAJOR else w_tiles
         self.keep.append(W)
         self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=mode, i3=i3, flags=flags, i4=addend_modulus, p0=L.ptr(W, strided=True),
@@ -150,7 +154,8 @@ class Program:
         per_pt = 0
         fixed = 0
         for o in self.ops:
-            if o.op in (L.OP_LOAD_PT, L.OP_STORE_PT, L.OP_ADD_PT, L.OP_MASK_POS, L.OP_ROWDOT_PT, L.OP_SOFTMAX_BWD):
+            if o.op in (L.OP_LOAD_PT, L.OP_STORE_PT, L.OP_ADD_PT, L.OP_MASK_POS, L.OP_ROWDOT_PT, L.OP_SOFTMAX_BWD,
+                        L.OP_LOAD_RM):
                 per_pt += 4 * o.i0
             elif o.op in (L.OP_LOAD_ROWS, L.OP_STORE_ROWS, L.OP_STORE_TR):
                 per_pt += 4 * o.i0
@@ -159,7 +164,7 @@ class Program:
             elif o.op == L.OP_LAYERNORM_BWD:
                 per_pt += 4 * pad32(o.i0) * (2 if o.p2 else 1)
             elif o.op == L.OP_LINEAR:
-                if o.flags & (L.F_ADD_PT | L.F_MASK_PT):
+                if o.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_ADD_RM):
                     per_pt += 4 * pad32(o.i1)
                 per_task = o.i2 != L.W_ROWMAJOR or o.s0 != 0
                 fixed += 4 * o.i0 * o.i1 * (self.n_tasks if per_task else 1)
@@ -268,6 +273,15 @@ class Chain:
         self.F = F
         return self
 
+    def input_rm(self, t: torch.Tensor, F: int, modulus: int = 0) -> "Chain":
+        """Row-major [n_tasks (or modulus), pts, F] input without a layout pass (F % 32 == 0, contiguous,
+        inference only: no gradient flows into it)."""
+        if F % 32 or not t.is_contiguous() or t.shape[-1] != F:
+            raise ValueError("input_rm needs a contiguous tensor with a multiple of 32 features")
+        self.steps.append(_Step("input_rm", {"x": self._t(t)}, {"F": F, "mod": modulus}))
+        self.F = F
+        return self
+
     def input_rows(self, t: torch.Tensor, kd: int, modulus: int = 0) -> "Chain":
         if kd > 32:
             raise NotImplementedError("row-major chain inputs are limited to 32 features")
@@ -278,10 +292,14 @@ class Chain:
     # ---- layers
     def linear(self, W: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
                addend: Optional[torch.Tensor] = None, addend_modulus: int = 0,
-               bias_per_task: bool = False) -> "Chain":
+               bias_per_task: bool = False, addend_rm: bool = False) -> "Chain":
         """cur <- act(W cur + b [+ addend]).  ``W`` [N, K] may be a column slice of a wider
-        matrix (row stride = ``W.stride(0)``); ``bias_per_task``: ``b`` is [n_tasks, pad32(N)]."""
+        matrix (row stride = ``W.stride(0)``); ``bias_per_task``: ``b`` is [n_tasks, pad32(N)];
+        ``addend_rm``: the addend is a row-major [n_tasks (or modulus), pts, N] tensor (N % 32 == 0,
+        inference only)."""
         N, K = W.shape
+        if addend_rm and (addend is None or N % 32 or not addend.is_contiguous() or addend.shape[-1] != N):
+            raise ValueError("a row-major addend must be contiguous with N % 32 == 0 features")
         if K != self.F:
             raise ValueError(f"Linear expects {K} inputs, chain carries {self.F}")
         if max(N, K) > L.NPF_MAX_FEATURES:
@@ -292,7 +310,8 @@ class Chain:
         if bias_per_task and not self.wg_per_task:
             raise ValueError("per-task biases need wg_per_task=True")
         self.steps.append(_Step("linear", {"W": self._t(W), "b": self._t(b), "add": self._t(addend)},
-                                {"N": N, "K": K, "relu": relu, "mod": addend_modulus, "bpt": bias_per_task}))
+                                {"N": N, "K": K, "relu": relu, "mod": addend_modulus, "bpt": bias_per_task,
+                                 "add_rm": addend_rm}))
         self.F = N
         return self
 
@@ -403,6 +422,12 @@ class _ChainFn(torch.autograd.Function):
                 prog.load_pt(T[st.t["x"]], a["F"], a["mod"])
                 backed = T[st.t["x"]] if a["mod"] == 0 else None
                 upstream = needs_grad[st.t["x"]]
+            elif k == "input_rm":
+                if train and needs_grad[st.t["x"]]:
+                    raise NotImplementedError("row-major chain inputs carry no gradient (inference path)")
+                prog.load_rm(T[st.t["x"]], a["F"], a["mod"])
+                backed = None
+                upstream = False
             elif k == "input_rows":
                 prog.load_rows(T[st.t["x"]], a["kd"], a["mod"])
                 backed = None
@@ -411,9 +436,11 @@ class _ChainFn(torch.autograd.Function):
                 W, b, add = st.t["W"], st.t["b"], st.t["add"]
                 if train and (needs_grad[W] or (b >= 0 and needs_grad[b])):
                     saved[(i, "in")] = ensure_saved(a["K"])
+                if a.get("add_rm") and train and (upstream or needs_grad[W] or needs_grad[add]):
+                    raise NotImplementedError("row-major addends carry no gradient (inference path)")
                 prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
                             addend=T[add] if add >= 0 else None, addend_modulus=a["mod"], ldw=T[W].stride(0),
-                            b_task_stride=(T[b].stride(0) if a["bpt"] else 0))
+                            b_task_stride=(T[b].stride(0) if a["bpt"] else 0), addend_rm=bool(a.get("add_rm")))
                 backed = None
                 upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if train and a["relu"] and upstream:

@@ -65,6 +65,14 @@ __device__ __forceinline__ const float* pt_lane(const void* base, const npf_prog
   return (const float*)base + tile * (size_t)(F * 32) + (16 * w.half + w.p) * 4;
 }
 
+// Pointer to the row of this lane's point in a row-major [task][pt][F] tensor (the lane's features
+// are at + 16 b + 4 g); padding points re-read the task's last point (loaded, never stored).
+__device__ __forceinline__ const float* rm_lane(const void* base, const npf_program_t& g, const Wave& w, int pt, int F,
+                                                int modulus) {
+  const int p = pt < g.pts_per_task ? pt : g.pts_per_task - 1;
+  return (const float*)base + ((size_t)eff_task(w, modulus) * g.pts_per_task + p) * (size_t)F;
+}
+
 // ---- weight slabs -------------------------------------------------------------------
 // A slab = rows [nb*32, nb*32+32) of a layer's weight matrix, all Kp = roundup(K, 32)
 // columns, as a dense [32][Kp] fp32 image in LDS whose 16-byte chunks are XOR-swizzled
@@ -628,8 +636,10 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       const bool relu = (o.flags & NPF_F_RELU) != 0;
       const bool mask = (o.flags & NPF_F_MASK_PT) != 0;  // out = (tile > 0) ? acc : 0  (relu backward)
       const bool add = ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid;
-      const float* addt = add ? pt_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4) : Z;
-      const int astep = add ? 128 : 0;  // (no addend: every load reads the zero buffer)
+      const bool add_rm = ((o.flags & NPF_F_ADD_RM) != 0) & w.valid;  // row-major addend: feature quad stride 4 floats
+      const float* addt = add ? pt_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4)
+                              : (add_rm ? rm_lane(o.p2, g, w, pt, N, o.i4) : Z);
+      const int astep = add ? 128 : (add_rm ? 4 : 0);  // (no addend: every load reads the zero buffer)
       NPF_STAMP(5)  // everything between LINEAR slab loops (other ops, layer setup)
       // Fast path for the 256 -> 256 layers (all the heavy ones at r = 256, attention included):
       // the 8 slab steps are unrolled, so the epilogue writes the slab's own two output blocks
@@ -748,6 +758,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         }
       }
       if (opc == NPF_OP_ROWDOT_PT) acc_dot = xg_sum(dot);
+    } else if (opc == NPF_OP_LOAD_RM) {
+      const int FB = o.i0 >> 4;
+      const float* t = rm_lane(o.p0, g, w, pt, o.i0, o.i4) + 4 * w.g;
+#pragma unroll
+      for (int b = 0; b < kMaxB16; ++b) {
+        if (b < FB) cur[b] = w.valid ? *(const f32x4*)(t + 16 * b) : zero4;
+      }
     } else if (opc == NPF_OP_STORE_PT) {
       const int FB = o.i0 >> 4;
       float* t = (float*)pt_lane(o.p0, g, w, o.i0, o.i4);
@@ -957,6 +974,9 @@ static int validate(const npf_program_t* g) {
         if (o.i2 != NPF_W_ROWMAJOR && (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
         if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) && (!o.p2 || (((uintptr_t)o.p2) & 15))) return NPF_EINVAL;
         if ((o.flags & NPF_F_ADD_PT) && (o.flags & NPF_F_MASK_PT)) return NPF_EINVAL;
+        if (o.flags & NPF_F_ADD_RM) {
+          if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) || !o.p2 || (((uintptr_t)o.p2) & 15) || (o.i1 & 31)) return NPF_EINVAL;
+        }
         if (o.s1 != 0 && !g->wg_per_task) return NPF_EINVAL;
         break;
       case NPF_OP_LOAD_PT:
@@ -968,6 +988,7 @@ static int validate(const npf_program_t* g) {
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || (o.i0 & 31) || !o.p0 || (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
         break;
       case NPF_OP_ADD_TASKVEC:
+      case NPF_OP_LOAD_RM:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || (o.i0 & 31) || !o.p0 || (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
         break;
       case NPF_OP_LOAD_ROWS:
@@ -1023,7 +1044,8 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
     const npf_op_t& o = g.ops[i];
     const bool feat_op = o.op == NPF_OP_LOAD_PT || o.op == NPF_OP_STORE_PT || o.op == NPF_OP_ADD_PT ||
                          o.op == NPF_OP_MASK_POS || o.op == NPF_OP_ROWDOT_PT || o.op == NPF_OP_SOFTMAX_BWD ||
-                         o.op == NPF_OP_ADD_TASKVEC || o.op == NPF_OP_SOFTMAX || o.op == NPF_OP_STORE_TR;
+                         o.op == NPF_OP_ADD_TASKVEC || o.op == NPF_OP_SOFTMAX || o.op == NPF_OP_STORE_TR ||
+                         o.op == NPF_OP_LOAD_RM;
     if (o.op == NPF_OP_LINEAR && (o.i0 > 256 || o.i1 > 256)) wide = true;
     if (feat_op && o.i0 > 256) wide = true;
   }
