@@ -8,6 +8,8 @@ Host code (Adam, all-reduce, control flow) is PyTorch, as the north star prescri
 """
 from __future__ import annotations
 
+import json
+import os
 from typing import Optional
 
 import torch
@@ -39,6 +41,12 @@ def synthetic_waveform_batch(B: int, C: int, T: int, seed: int, device, dx: int 
     return dict(X_cntxt=take(X, ci), Y_cntxt=take(Y, ci), X_trgt=take(X, ti), Y_trgt=take(Y, ti))
 
 
+def get_exponential_decay_gamma(scheduling_factor, max_epochs):
+    """Per-epoch factor that reduces the learning rate by ``scheduling_factor`` over ``max_epochs``
+    (utils/helpers.py:35-46, used with ExponentialLR in utils/train.py:233-237)."""
+    return (1 / scheduling_factor) ** (1 / max_epochs)
+
+
 class Trainer:
     """forward -> loss -> backward -> (bucketed all-reduce) -> Adam, on flat parameter /
     gradient buffers."""
@@ -63,3 +71,39 @@ class Trainer:
         self.flat.flat.grad = self.reducer.finish()
         self.opt.step()
         return loss.detach()
+
+    # ---- what the reference gets from skorch callbacks (utils/train.py:203-241) ------------------
+    def set_lr_decay(self, decay_lr: float, max_epochs: int) -> None:
+        """Exponential decay by ``decay_lr`` in total over ``max_epochs`` (ExponentialLR per epoch)."""
+        self._sched = torch.optim.lr_scheduler.ExponentialLR(self.opt, gamma=get_exponential_decay_gamma(decay_lr, max_epochs))
+
+    def end_epoch(self) -> float:
+        """Advance the learning-rate schedule (if any); returns the new learning rate."""
+        if getattr(self, "_sched", None) is not None:
+            self._sched.step()
+        return self.opt.param_groups[0]["lr"]
+
+    def save_checkpoint(self, dirname: str, history: Optional[list] = None) -> None:
+        """skorch ``Checkpoint`` layout: ``params.pt`` = the module's state_dict (the reference's key
+        names, loadable by the reference and by ``load_state_dict`` here), ``optimizer.pt``,
+        ``history.json``.  The optimizer state is Adam's on the *flat* parameter buffer (one
+        exp_avg / exp_avg_sq vector): it resumes this Trainer, it is not skorch's per-tensor state."""
+        os.makedirs(dirname, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, os.path.join(dirname, "params.pt"))
+        torch.save(self.opt.state_dict(), os.path.join(dirname, "optimizer.pt"))
+        with open(os.path.join(dirname, "history.json"), "w") as f:
+            json.dump(history or [], f)
+
+    def load_checkpoint(self, dirname: str, load_optimizer: bool = True) -> list:
+        """Inverse of :meth:`save_checkpoint`; ``params.pt`` may also be one written by the reference
+        (e.g. ``results/pretrained/*/run_0/params.pt``).  Loaded with ``weights_only=True``."""
+        sd = torch.load(os.path.join(dirname, "params.pt"), map_location="cpu", weights_only=True)
+        self.model.load_state_dict(sd, strict=True)  # parameters are views of the flat buffer: copied in place
+        opt_path = os.path.join(dirname, "optimizer.pt")
+        if load_optimizer and os.path.exists(opt_path):
+            try:
+                self.opt.load_state_dict(torch.load(opt_path, map_location=self.flat.flat.device, weights_only=True))
+            except (ValueError, KeyError, RuntimeError) as e:  # e.g. skorch's per-tensor optimizer state
+                raise ValueError(f"{opt_path} does not hold this Trainer's flat Adam state: {e}") from e
+        hist = os.path.join(dirname, "history.json")
+        return json.load(open(hist)) if os.path.exists(hist) else []

@@ -276,3 +276,28 @@ def test_index_getters_follow_reference_contract():
         A.GetRandomIndcs(a=-1, b=2)(2, 10)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         A.CntxtTrgtGetter()(torch.zeros(2, 10, 1), torch.zeros(2, 10, 2))
+
+
+def test_trainer_checkpoint_and_lr_schedule_glue(tmp_path):
+    """Checkpoint files in skorch's layout (params.pt with the reference's keys, optimizer.pt,
+    history.json) and the exponential LR decay of utils/helpers.py:35-46 (CPU: no step taken)."""
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd.train import Trainer, get_exponential_decay_gamma
+
+    assert abs(get_exponential_decay_gamma(10, 100) ** 100 - 0.1) < 1e-12
+    m1, m2 = _model("CNP", r_dim=32), _model("CNP", r_dim=32)
+    t1, t2 = Trainer(m1, A.CNPFLoss(), lr=1e-3, world=1), Trainer(m2, A.CNPFLoss(), lr=5e-4, world=1)
+    t1.set_lr_decay(10, 4)
+    lrs = [t1.end_epoch() for _ in range(4)]
+    assert abs(lrs[-1] - 1e-4) < 1e-12 and lrs[0] > lrs[1] > lrs[2] > lrs[3]
+    t1.save_checkpoint(str(tmp_path / "ck"), history=[{"epoch": 1, "train_loss": 3.5}])
+    assert sorted(os.listdir(tmp_path / "ck")) == ["history.json", "optimizer.pt", "params.pt"]
+    sd = torch.load(tmp_path / "ck" / "params.pt", weights_only=True)
+    assert set(sd) == set(m1.state_dict())
+    assert not torch.equal(m1.decoder.flat_module.out.weight, m2.decoder.flat_module.out.weight)
+    hist = t2.load_checkpoint(str(tmp_path / "ck"))
+    assert hist[0]["train_loss"] == 3.5
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert t2.flat.params[0].data_ptr() == t2.flat.flat.data_ptr()  # still views of the flat buffer
+    assert abs(t2.opt.param_groups[0]["lr"] - 1e-4) < 1e-12
