@@ -4,7 +4,7 @@ MarinerQ/npf_GWwaveform, behind the reference's own module API.  See DESIGN.md.
 The compute runs in hand-written HIP kernels (``csrc/``) reached through a C ABI
 (``include/npf_hip.h``); there is no CPU or eager-PyTorch fallback for the path.
 """
-from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, TransformerAttender, get_attender,
+from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, SelfAttention, TransformerAttender, get_attender,
                             merge_flat_input)
 from .datasplit import CntxtTrgtGetter, GetRandomIndcs, GetRangeIndcs, get_all_indcs
 from .losses import CNPFLoss, ELBOLossLNPF, LightTailPareto, NLLLossLNPF, SUMOLossLNPF
@@ -33,7 +33,7 @@ def decode(model: NeuralProcessFamily, X_trgt_enc, R_trgt):
 
 
 __all__ = [
-    "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "get_attender",
+    "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "SelfAttention", "get_attender",
     "NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP", "NPFModel",
     "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "SUMOLossLNPF", "LightTailPareto", "MultivariateNormalDiag", "encode", "aggregate", "decode",
     "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs",

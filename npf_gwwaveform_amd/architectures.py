@@ -29,7 +29,7 @@ from ._lib import NPF_MAX_TRAIN_FEATURES
 from .chain import Chain
 
 __all__ = ["MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender",
-           "get_attender"]
+           "SelfAttention", "get_attender"]
 
 
 def _check_relu(activation) -> None:
@@ -136,8 +136,8 @@ class MergeFlatInputs(nn.Module):
         self.is_sum_merge = True
         self.resizer = MLP(x2_dim, x1_dim)
         self.flat_module = FlatModule(x1_dim, n_out, **kwargs)
-        if not isinstance(self.flat_module, MLP):
-            raise NotImplementedError("the HIP path needs an MLP as the flat module")
+        if not isinstance(self.flat_module, (MLP, SelfAttention)):
+            raise NotImplementedError("the HIP path needs an MLP or a SelfAttention as the flat module")
 
     def reset_parameters(self):  # the reference's weights_init is a no-op here
         pass
@@ -150,7 +150,27 @@ class MergeFlatInputs(nn.Module):
         for j, lin in enumerate(rl[:-1]):
             ch.linear(lin.weight, lin.bias, relu=True)
         ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=x1_modulus, addend_rm=x1_rm)
+        if isinstance(self.flat_module, SelfAttention):
+            raise NotImplementedError("a SelfAttention flat module is not one chain: use run_pt")
         return self.flat_module.append_to(ch)
+
+    def run_pt(self, ch: Chain, x1_pt, n_tasks: int, pts: int, with_tr: bool = False, **kw):
+        """Finish ``ch`` (cur = x2) with this module and run it: PT32 output [n_tasks, pts, n_out]
+        (with ``_npf_tr`` set to the feature-major copy when ``with_tr``).  One launch for an MLP flat
+        module; for a SelfAttention flat module the merge is a launch and the attention layers follow."""
+        if isinstance(self.flat_module, MLP):
+            self.append_to(ch, x1_pt=x1_pt, **kw).output_pt()
+            if with_tr:
+                ch.store_tr()
+            outs = ch.run()
+            if with_tr:
+                outs[0]._npf_tr = outs[1]
+            return outs[0]
+        rl = self.resizer.layers()
+        for lin in rl[:-1]:
+            ch.linear(lin.weight, lin.bias, relu=True)
+        ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=kw.get("x1_modulus", 0)).output_pt()
+        return self.flat_module.forward_pt(ch.run()[0], n_tasks, pts, with_tr=with_tr)
 
     def forward(self, x1, x2):
         # row-major API: x1 [..., T, x1_dim]; x2 broadcastable to it with optional extra leading dims
@@ -166,6 +186,11 @@ class MergeFlatInputs(nn.Module):
         n_out = self.flat_module.output_size
         if T == 0 or n2 == 0:
             return x1.new_zeros(*lead2, T, n_out)
+        if isinstance(self.flat_module, SelfAttention):
+            ch = Chain(n2, T, x1.device)
+            ch.input_pt(FN.pack_pt(x2.reshape(n2, T, x2.shape[-1])), x2.shape[-1])
+            y = self.run_pt(ch, FN.pack_pt(x1.reshape(n1, T, d1)), n2, T, x1_modulus=(n1 if n1 != n2 else 0))
+            return FN.unpack_pt(y, T, n_out).reshape(*lead2, T, n_out)
         ch = Chain(n2, T, x1.device)
         d2 = x2.shape[-1]
         no_grad = not torch.is_grad_enabled() or not (x1.requires_grad or x2.requires_grad or
@@ -222,8 +247,15 @@ class DotAttender(nn.Module):
         return n_keys <= NPF_MAX_TRAIN_FEATURES
 
     def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
-        """PT32 in, PT32 out, any number of keys (blocked softmax, attention_long.py)."""
+        """PT32 in, PT32 out, any number of keys (fused chain up to 256 keys, blocked softmax of
+        attention_long.py beyond)."""
         from .attention_long import long_scaledot_attention
+
+        if self.fits_fused(n_keys):
+            ch = Chain(queries_pt.shape[0], n_queries, queries_pt.device, wg_per_task=True)
+            ch.input_pt(queries_pt, self.kq_size)
+            self.append_to(ch, keys_pt, values_pt, n_keys, keys_tr=keys_tr, values_tr=values_tr).output_pt()
+            return ch.run()[0]
 
         scale = 1.0 / math.sqrt(self.kq_size) if self.is_scale else 1.0
         return long_scaledot_attention(queries_pt, keys_pt, values_pt, n_keys, n_queries, self.value_size, scale,
@@ -348,6 +380,56 @@ class TransformerAttender(MultiheadAttender):
             ch.linear(lin.weight, lin.bias, relu=True)
         ch.linear(ls[-1].weight, ls[-1].bias, addend=x).layernorm(ln2.weight, ln2.bias, ln2.eps).output_pt()
         return ch.run()[0]
+
+
+class SelfAttention(nn.Module):
+    """Stack of self-attention layers over the points of each task (npf/architectures/selfattn.py:10-100):
+    ``out = layer(out, out, out)`` for ``n_attn_layers`` attenders, then an optional resize Linear.
+    Positional encodings (absolute / relative) are not on the hot path."""
+
+    def __init__(self, x_dim, out_dim=None, n_attn_layers=2, attention="transformer", positional=None, position_dim=None,
+                 max_len=2000, **kwargs):
+        super().__init__()
+        if positional is not None:
+            raise NotImplementedError("positional encodings are not on the hot path")
+        self.positional = None
+        self.attn_layers = nn.ModuleList([get_attender(attention, x_dim, x_dim, x_dim, **kwargs) for _ in range(n_attn_layers)])
+        for layer in self.attn_layers:
+            if not hasattr(layer, "attend_pt"):
+                raise NotImplementedError("self attention needs one of the attenders of this package")
+        self.is_resize = out_dim is not None
+        self.x_dim, self.out_dim = x_dim, (out_dim if out_dim is not None else x_dim)
+        if self.is_resize:
+            self.resize = nn.Linear(x_dim, out_dim)
+
+    def reset_parameters(self):  # weights_init is a no-op (SURVEY.md 8a row 12)
+        pass
+
+    def forward_pt(self, x_pt, n_tasks: int, pts: int, with_tr: bool = False):
+        out = x_pt
+        for layer in self.attn_layers:
+            out = layer.attend_pt(out, out, out, pts, pts)
+        if self.is_resize or with_tr:
+            ch = Chain(n_tasks, pts, x_pt.device)
+            ch.input_pt(out, self.x_dim)
+            if self.is_resize:
+                ch.linear(self.resize.weight, self.resize.bias)
+            ch.output_pt()
+            if with_tr:
+                ch.store_tr()
+            outs = ch.run()
+            out = outs[0]
+            if with_tr:
+                out._npf_tr = outs[1]
+        return out
+
+    def forward(self, X, positions=None):
+        if positions is not None:
+            raise NotImplementedError("positional encodings are not on the hot path")
+        lead, P, d = X.shape[:-2], X.shape[-2], X.shape[-1]
+        n = int(math.prod(lead)) if len(lead) else 1
+        out = self.forward_pt(FN.pack_pt(X.reshape(n, P, d)), n, P)
+        return FN.unpack_pt(out, P, self.out_dim).reshape(*lead, P, self.out_dim)
 
 
 def get_attender(attention, kq_size, value_size, out_size, **kwargs):

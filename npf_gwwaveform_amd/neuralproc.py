@@ -26,7 +26,8 @@ import torch.nn as nn
 from torch.distributions import Independent, Normal
 
 from . import functional as FN
-from .architectures import MLP, DotAttender, MergeFlatInputs, MultiheadAttender, get_attender, merge_flat_input
+from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, SelfAttention, get_attender,
+                            merge_flat_input)
 from .chain import Chain, pad32
 
 __all__ = ["NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP",
@@ -156,13 +157,7 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         """Per-point XY encoding (the per-point part of encode_globally) -> PT32 [B, P, r]."""
         ch = Chain(B, P, Y.device)
         ch.input_rows(Y.contiguous(), self.y_dim)
-        self.xy_encoder.append_to(ch, x1_pt=X_enc_pt).output_pt()
-        if self._attentive:
-            ch.store_tr()
-        outs = ch.run()
-        if self._attentive:
-            outs[0]._npf_tr = outs[1]
-        return outs[0]
+        return self.xy_encoder.run_pt(ch, X_enc_pt, B, P, with_tr=self._attentive)
 
     def _head(self, suff, Y_trgt, B, T):
         n_rows = suff.shape[0]
@@ -399,8 +394,9 @@ class AttnCNP(NeuralProcessFamily):
         super().__init__(x_dim, y_dim, **kwargs)
         self.is_self_attn = is_self_attn
         if is_self_attn:
-            raise NotImplementedError("self-attention encoders are not on the hot path (SURVEY.md 8f N4)")
-        if XYEncoder is None:
+            # attnnp.py:88-91: relu(x + resizer(y)) followed by self-attention layers over the context
+            XYEncoder = merge_flat_input(SelfAttention, is_sum_merge=True, **self_attention_kwargs)
+        elif XYEncoder is None:
             XYEncoder = self.dflt_Modules["XYEncoder"]
         self.xy_encoder = XYEncoder(self.x_transf_dim, self.y_dim, self.r_dim)
         if not isinstance(self.xy_encoder, MergeFlatInputs):

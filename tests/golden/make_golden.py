@@ -255,6 +255,38 @@ def run_pretrained_attn():
     np.savez_compressed(os.path.join(HERE, "g9_pretrained_attn.npz"), **res)
 
 
+def run_selfattn_case():
+    """G11: AttnCNP with the self-attention XY-encoder (attnnp.py:88-91,
+    selfattn.py:10-100) and transformer cross attention.  The reference's own seeded init is stored in
+    the fixture (no oracle restatement of this variant: the fixture pins the HIP path directly)."""
+    torch.manual_seed(11)
+    rng = np.random.Generator(np.random.Philox(11))
+    f = lambda a: torch.from_numpy(np.asarray(a, dtype="float32"))  # noqa: E731
+    B, C, T, r = 3, 14, 30, 32
+    Xc, Yc = f(rng.uniform(-1, 1, (B, C, 1))), f(rng.standard_normal((B, C, 2)))
+    Xt, Yt = f(rng.uniform(-1, 1, (B, T, 1))), f(rng.standard_normal((B, T, 2)))
+    model = npf.AttnCNP(1, 2, r_dim=r, attention="transformer", is_self_attn=True)
+    with torch.no_grad():  # non-trivial biases / LayerNorm weights
+        for k, p in model.named_parameters():
+            if k.endswith(".bias"):
+                p.copy_(f(rng.uniform(-0.05, 0.05, tuple(p.shape))))
+            elif "layer_norm" in k:
+                p.copy_(f(rng.uniform(0.5, 1.5, tuple(p.shape))))
+    res = {"X_cntxt": Xc.numpy(), "Y_cntxt": Yc.numpy(), "X_trgt": Xt.numpy(), "Y_trgt": Yt.numpy()}
+    for k, v in model.state_dict().items():
+        res[f"param/{k}"] = v.numpy().copy()
+    model.train()
+    crit = npf.CNPFLoss()
+    out = model(Xc, Yc, Xt, Yt)
+    loss = crit(out, Yt)
+    loss.backward()
+    res["loc"], res["scale"], res["loss"] = out[0].base_dist.loc.detach().numpy(), out[0].base_dist.scale.detach().numpy(), loss.detach().numpy()
+    for k, p in model.named_parameters():
+        res[f"grad/{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g11_attncnp_selfattn.npz"), **res)
+    print("g11_attncnp_selfattn: loss", float(loss), "n_params", sum(p.numel() for p in model.parameters()))
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
     if only:  # e.g. `make_golden.py g8_ g9` regenerates the matching cases only
@@ -263,6 +295,8 @@ if __name__ == "__main__":
                 run_case(name, case, store_params=False, store_full_grads=case["r"] < 256)
         if any(o.startswith("g9") for o in only):
             run_pretrained_attn()
+        if any(o.startswith("g11") for o in only):
+            run_selfattn_case()
         sys.exit(0)
     small_full = {"g1_cnp_c1", "g2_lnp_both_c1", "g2_lnp_latent_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64",
                   "g4s_attnlnp_r64_noqzcct"}
@@ -274,3 +308,4 @@ if __name__ == "__main__":
     run_stage_cases()
     run_pretrained()
     run_pretrained_attn()
+    run_selfattn_case()

@@ -347,3 +347,30 @@ def test_context_target_getter_matches_reference_selection():
     loss = A.CNPFLoss()(model(Xc, Yc, Xt, Yt), Yt)
     loss.backward()
     assert torch.isfinite(loss)
+
+
+def test_self_attention_encoder_matches_reference():
+    """G11: AttnCNP(is_self_attn=True, attention="transformer") -- relu(x + resizer(y))
+    followed by two transformer self-attention layers over the context (selfattn.py:10-100), then
+    transformer cross attention -- against the reference's forward / loss / gradients on its own
+    seeded weights (tests/golden/g11_attncnp_selfattn.npz)."""
+    import warnings
+
+    import npf_gwwaveform_amd as A
+
+    g = specs.load_golden("g11_attncnp_selfattn")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = A.AttnCNP(1, 2, r_dim=32, attention="transformer", is_self_attn=True)
+    model.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}, strict=True)
+    model = model.to(DEV).train()
+    Xc, Yc, Xt, Yt = (torch.from_numpy(g[k]).to(DEV) for k in ("X_cntxt", "Y_cntxt", "X_trgt", "Y_trgt"))
+    out = model(Xc, Yc, Xt, Yt)
+    loss = A.CNPFLoss()(out, Yt)
+    loss.backward()
+    assert_close(out[0].base_dist.loc, g["loc"], what="loc")
+    assert_close(out[0].base_dist.scale, g["scale"], what="scale")
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=2e-5)
+    for k, p in model.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(got, g[f"grad/{k}"], tol=1e-4, what=f"grad {k}")

@@ -138,7 +138,7 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         A.AttnCNP(1, 1, attention="transformer", attention_kwargs=dict(dropout=0.1))
     with pytest.raises(NotImplementedError):
-        A.AttnCNP(1, 1, is_self_attn=True)
+        A.AttnCNP(1, 1, is_self_attn=True, self_attention_kwargs=dict(positional="absolute", position_dim=1))
     with pytest.raises(NotImplementedError):
         A.MLP(4, 4, activation=torch.nn.GELU())
     with pytest.raises(NotImplementedError):
