@@ -20,6 +20,7 @@
  *   npf_mean_agg_fwd/bwd torch.mean(R_cntxt, dim=1)       npf/neuralproc/np.py:95, attnnp.py:181
  *   npf_pack_pt/unpack_pt  layout change at the module boundary (no reference counterpart)
  *   npf_transpose        W -> W^T for the dgrad chains (no reference counterpart)
+ *   npf_cast_bf16_weights  bf16 weight images for the bf16 compute mode (no reference counterpart)
  *   npf_gather_points    CntxtTrgtGetter.select              npf/utils/datasplit.py:246-255
  *   npf_split_heads/npf_merge_heads  MultiheadAttender._make_multiheaded / _concatenate_multiheads
  *                                                         npf/architectures/attention.py:505-527
@@ -205,6 +206,15 @@ int npf_merge_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int
  * idx: int64 [n_tasks][n_sel], every entry in [0, n_points) (checked on the host side). */
 int npf_gather_points(const float *x, const float *y, const int64_t *idx, int32_t n_tasks, int32_t n_points,
                       int32_t n_sel, int32_t x_dim, int32_t y_dim, float *out_x, float *out_y, void *stream);
+
+/* bf16 compute mode of the chain kernel (prog->reserved[2] == 1): every LINEAR op takes, instead of fp32
+ * weights, the bf16 image this function writes -- dst [rows][roundup(cols, 32)] bf16, columns permuted
+ * inside each group of 32 (position 8g+i <- column 4g+i, position 8g+4+i <- column 16+4g+i), zero
+ * padded -- with p0 = dst, i3 = roundup(K, 32) / 2 (row stride in floats), NPF_W_ROWMAJOR.  Activations
+ * are rounded to bf16 at the MFMA input, accumulation / bias / epilogue / HBM tensors stay fp32.
+ * transposed != 0: the image of src^T (rows = columns of src), for the dgrad chains. */
+int npf_cast_bf16_weights(const float *src, int32_t n_rows, int32_t n_cols, int32_t ld, int32_t transposed, void *dst,
+                          void *stream);
 
 /* Library / device info. */
 int npf_version(void);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "npf_pack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "npf_unpack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "npf_transpose": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "npf_cast_bf16_weights": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_gather_points": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "npf_split_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_merge_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),

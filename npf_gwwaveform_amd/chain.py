@@ -66,6 +66,7 @@ class Program:
         self.n_tasks, self.pts, self.wg_per_task = n_tasks, pts_per_task, wg_per_task
         self.ops: List[L.NpfOp] = []
         self.keep: list = []  # tensors referenced by raw pointer must outlive the launch call
+        self.bf16 = False     # every LINEAR takes a bf16 weight image (linear_bf16)
 
     def _op(self, **kw) -> None:
         if len(self.ops) >= L.NPF_MAX_OPS:
@@ -136,11 +137,25 @@ class Program:
 
     def linear(self, W, K, N, bias=None, relu=False, addend=None, addend_modulus=0, mode=L.W_ROWMAJOR, ldw=None,
                w_tiles=0, w_task_stride=0, b_task_stride=0, addend_rm=False):
+        if self.bf16:
+            raise ValueError("a program is either all-fp32 or all-bf16")
         flags = (L.F_RELU if relu else 0) | ((L.F_ADD_RM if addend_rm else L.F_ADD_PT) if addend is not None else 0)
         i3 = (ldw if ldw is not None else K) if mode == L.W_ROWMAJOR else w_tiles
         self.keep.append(W)
         self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=mode, i3=i3, flags=flags, i4=addend_modulus, p0=L.ptr(W, strided=True),
                  p1=self._p(bias), p2=self._p(addend), s0=w_task_stride, s1=b_task_stride)
+
+    def linear_bf16(self, W_img, K, N, bias=None, relu=False, addend=None, addend_modulus=0, b_task_stride=0):
+        """LINEAR in the bf16 compute mode: ``W_img`` = ``cast_bf16_weights`` image [N, pad32(K)] (bf16)."""
+        if self.ops and not self.bf16 and any(o.op == L.OP_LINEAR for o in self.ops):
+            raise ValueError("a program is either all-fp32 or all-bf16")
+        if W_img.dtype != torch.bfloat16 or tuple(W_img.shape) != (N, pad32(K)) or not W_img.is_contiguous():
+            raise ValueError(f"bf16 weight image must be contiguous [N, pad32(K)] bfloat16, got {tuple(W_img.shape)} {W_img.dtype}")
+        self.bf16 = True
+        flags = (L.F_RELU if relu else 0) | (L.F_ADD_PT if addend is not None else 0)
+        self.keep.append(W_img)
+        self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=L.W_ROWMAJOR, i3=pad32(K) // 2, flags=flags, i4=addend_modulus,
+                 p0=W_img.data_ptr(), p1=self._p(bias), p2=self._p(addend), s0=0, s1=b_task_stride)
 
     def flops(self) -> int:
         """Algorithmic GEMM FLOPs of one launch: 2*K*N per LINEAR per valid point."""
@@ -189,6 +204,7 @@ class Program:
         prog.wg_per_task = int(self.wg_per_task)
         prog.reserved[0] = DEBUG_ABLATE
         prog.reserved[1] = FORCE_WG
+        prog.reserved[2] = int(self.bf16)
         for i, o in enumerate(self.ops):
             prog.ops[i] = o
         L.check(L.load().npf_chain_run(C.byref(prog), L.stream_ptr()), "npf_chain_run")
@@ -229,6 +245,19 @@ def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         L.check(lib.npf_wgrad_run(arr, len(chunk), n_tasks, tiles_of(pts), L.ptr(ws), nbytes, L.stream_ptr()),
                 "npf_wgrad_run")
+
+
+def cast_bf16_weights(W: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """The bf16 image of a row-major fp32 matrix ``W`` [N, K] (or of ``W^T``) that the bf16 chain instance
+    streams: [rows, pad32(cols)] bfloat16, k-permuted inside groups of 32 (``npf_cast_bf16_weights``)."""
+    N, K = W.shape
+    if W.stride(1) != 1:
+        raise ValueError("weight rows must be contiguous")
+    rows, cols = (K, N) if transposed else (N, K)
+    out = torch.empty((rows, pad32(cols)), dtype=torch.bfloat16, device=W.device)
+    L.check(L.load().npf_cast_bf16_weights(L.ptr(W, strided=True), N, K, W.stride(0), int(transposed), out.data_ptr(),
+                                           L.stream_ptr()), "npf_cast_bf16_weights")
+    return out
 
 
 def transpose(W: torch.Tensor) -> torch.Tensor:

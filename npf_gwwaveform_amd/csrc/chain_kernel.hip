@@ -106,9 +106,12 @@ struct SlabOp {
   int n_pw;         // pieces per wave per slab
 };
 
+// BF16: the weights are a bf16 image ([N][roundup(K, 32)] bf16, k-permuted inside each group of 32, see
+// npf_cast_bf16_weights): for the slab stream it is simply a matrix of K/2 floats per row.
+template <bool BF16>
 __device__ __forceinline__ SlabOp make_slab_op(const npf_op_t& o, int task) {
   SlabOp s;
-  s.K = o.i0;
+  s.K = BF16 ? (((o.i0 + 31) >> 5) * 16) : o.i0;
   s.N = o.i1;
   s.mode = o.i2;
   s.Kp = ((s.K + 31) >> 5) * 32;
@@ -121,7 +124,7 @@ __device__ __forceinline__ SlabOp make_slab_op(const npf_op_t& o, int task) {
   const float* W = (const float*)o.p0;
   if (s.mode == NPF_W_ROWMAJOR) {
     s.W = W + (size_t)task * o.s0;
-    s.vec16 = ((o.i3 & 3) == 0) && ((o.i0 & 3) == 0) && ((o.s0 & 3) == 0) && ((((uintptr_t)o.p0) & 15) == 0);
+    s.vec16 = ((o.i3 & 3) == 0) && ((s.K & 3) == 0) && ((o.s0 & 3) == 0) && ((((uintptr_t)o.p0) & 15) == 0);
   } else if (s.mode == NPF_W_PT_ROWS) {
     s.W = W + (size_t)task * o.i3 * (size_t)(s.Kp * 32);  // + tile * Kp * 32 per 32 rows
     s.vec16 = true;
@@ -387,6 +390,46 @@ __device__ __forceinline__ void slab_mfma_any(const float* slot, int KB16, const
   }
 }
 
+// bf16 instance: one k-step = 32 features = the lane's own values of two adjacent 16-row blocks of the
+// previous layer (packed to bf16 once per layer, `curb`), against one 16-byte fragment of the k-permuted
+// bf16 weight image per output block: v_mfma_f32_16x16x32_bf16, fp32 accumulation.  The LDS image is
+// the fp32 one with rows of KpF = roundup(K/2, 32) floats (same swizzle, same fragment addresses).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 pack_bf16(const f32x4& lo, const f32x4& hi) {
+  const bf16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), bf16x2), p1 = __builtin_convertvector((f32x2{lo[2], lo[3]}), bf16x2);
+  const bf16x2 p2 = __builtin_convertvector((f32x2{hi[0], hi[1]}), bf16x2), p3 = __builtin_convertvector((f32x2{hi[2], hi[3]}), bf16x2);
+  bf16x8 r;
+  r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
+  r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
+  return r;
+}
+
+template <int NBLK, int MAXB>
+__device__ __forceinline__ void slab_mfma_bf16(const float* slot, int KpF, int S, const Wave& w,
+                                               const bf16x8 (&curb)[MAXB / 2], f32x4 (&acc)[kBlk]) {
+  const int cpr = KpF >> 2;
+  const int swz = (cpr & 15) ? 7 : 15;
+  const int ps = w.p & swz;
+  const float* a = slot + w.p * KpF;
+  const float* bias = slot + kSlabRows * KpF + 4 * w.g;
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) acc[j] = *(const f32x4*)(bias + 16 * j);
+#pragma unroll
+  for (int st = 0; st < MAXB / 2; ++st) {
+    if (st < S) {
+      const int off = (((4 * st + w.g) ^ ps) << 2);
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) {
+        const f32x4 x = *(const f32x4*)(a + j * 16 * KpF + off);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), curb[st], acc[j], 0, 0, 0);
+      }
+    }
+  }
+}
+
 // The 256-feature slab loop of the fast path: the pinned fragment pipeline of slab_mfma<2, 16>
 // accumulating straight into the slab's two output blocks, plus `side(kb)` after the MFMAs of
 // every 16-feature block.  A wave's own VMEM / VALU instructions issue in the shadow of its own
@@ -537,7 +580,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 // FKB, FNB: the one layer shape (K = 16 FKB, N = 32 FNB) this instance runs software-pipelined
 // (0: none).  One shape per instance: two pipelined shapes in one kernel make hipcc spill inside the
 // MFMA loops; the launcher picks the instance by the program's most frequent square layer.
-template <int MAXB, int WAVES, bool EXTRA, int FKB, int FNB>
+// BF16: the instance whose LINEAR ops multiply in bf16 (weights = bf16 images, activations rounded to
+// bf16 at the MFMA input, fp32 accumulation, fp32 registers / epilogue / HBM tensors); shared row-major
+// weights only, generic slab loop.
+template <int MAXB, int WAVES, bool EXTRA, int FKB, int FNB, bool BF16>
 __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) void chain_kernel(const npf_program_t g) {
   constexpr int kMaxB16 = MAXB;
   constexpr int kSlabFloats = slab_floats(MAXB);
@@ -602,7 +648,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
     while (pf.op < g.n_ops && g.ops[pf.op].op != NPF_OP_LINEAR) ++pf.op;
     pf.nb = 0;
     if (pf.op < g.n_ops) {
-      pfs = make_slab_op(g.ops[pf.op], wg_task);
+      pfs = make_slab_op<BF16>(g.ops[pf.op], wg_task);
       slab_fast_setup(pfs, w);
     }
   };
@@ -632,6 +678,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
     const int opc = o.op;
     if (opc == NPF_OP_LINEAR) {
       const int KB16 = ((o.i0 + 31) >> 5) * 2, N = o.i1;
+      // bf16 instance: LDS row length in floats and number of 32-feature k-steps; the layer's input packed
+      [[maybe_unused]] const int bf_kpf = ((((o.i0 + 31) >> 5) * 16 + 31) >> 5) * 32, bf_steps = (o.i0 + 31) >> 5;
+      [[maybe_unused]] bf16x8 curb[kMaxB16 / 2];
+      if constexpr (BF16) {
+#pragma unroll
+        for (int st = 0; st < kMaxB16 / 2; ++st) curb[st] = pack_bf16(cur[2 * st], cur[2 * st + 1]);
+      }
       const int NB = (N + kSlabRows - 1) / kSlabRows;
       const bool relu = (o.flags & NPF_F_RELU) != 0;
       const bool mask = (o.flags & NPF_F_MASK_PT) != 0;  // out = (tile > 0) ? acc : 0  (relu backward)
@@ -700,8 +753,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
           NPF_STAMP(4)      // (group B) barrier wait
         }
         if (!(g.reserved[0] & 8)) {
-          if (N - nb * kSlabRows > 16) slab_mfma_any<2, MAXB>(sl, KB16, w, cur, acc);
-          else slab_mfma_any<1, MAXB>(sl, KB16, w, cur, acc);
+          if constexpr (BF16) {
+            if (N - nb * kSlabRows > 16) slab_mfma_bf16<2, MAXB>(sl, bf_kpf, bf_steps, w, curb, acc);
+            else slab_mfma_bf16<1, MAXB>(sl, bf_kpf, bf_steps, w, curb, acc);
+          } else {
+            if (N - nb * kSlabRows > 16) slab_mfma_any<2, MAXB>(sl, KB16, w, cur, acc);
+            else slab_mfma_any<1, MAXB>(sl, KB16, w, cur, acc);
+          }
         }
         NPF_STAMP(1)  // addend loads + MFMA loop
         if (!grp_b && !(g.reserved[0] & 4)) __syncthreads();  // slab consumed; vmcnt(0) lands the next one
@@ -968,7 +1026,7 @@ static int validate(const npf_program_t* g) {
         if (o.i2 < 0 || o.i2 > 2) return NPF_EINVAL;
         if (o.i2 != NPF_W_ROWMAJOR && !g->wg_per_task) return NPF_EINVAL;  // per-task weights
         if (o.i2 == NPF_W_ROWMAJOR && o.s0 != 0 && !g->wg_per_task) return NPF_EINVAL;
-        if (o.i2 == NPF_W_ROWMAJOR && o.i3 < o.i0) return NPF_EINVAL;
+        if (o.i2 == NPF_W_ROWMAJOR && o.i3 < (g->reserved[2] == 1 ? ((o.i0 + 31) >> 5) * 16 : o.i0)) return NPF_EINVAL;
         if (o.i2 == NPF_W_PT_ROWS && o.i3 * 32 < o.i1) return NPF_EINVAL;
         if (o.i2 == NPF_W_PT_COLS && o.i3 * 32 < o.i0) return NPF_EINVAL;
         if (o.i2 != NPF_W_ROWMAJOR && (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
@@ -1066,18 +1124,32 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
     }
   }
   if (extra && wide) return NPF_EINVAL;
+  // reserved[2] == 1: every LINEAR of the program takes a bf16 weight image (npf_cast_bf16_weights)
+  const bool bf16 = g.reserved[2] == 1;
+  if (bf16) {
+    if (extra || wide) return NPF_EINVAL;
+    for (int i = 0; i < g.n_ops; ++i) {
+      const npf_op_t& o = g.ops[i];
+      if (o.op == NPF_OP_LINEAR && (o.i2 != NPF_W_ROWMAJOR || (((uintptr_t)o.p0) & 15) || o.i3 < ((o.i0 + 31) >> 5) * 16))
+        return NPF_EINVAL;
+    }
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 0, 0, true>), dim3((unsigned)grid_for(2)), dim3(256), 0,
+                       (hipStream_t)stream, g);
+    NPF_CHECK_LAUNCH();
+    return NPF_OK;
+  }
   const dim3 b4(256), b8(512);
   const hipStream_t st = (hipStream_t)stream;
   if (extra)
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4, true, 0, 0>), dim3((unsigned)grid_for(2)), b4, 0, st, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, true, 0, 0, false>), dim3((unsigned)grid_for(2)), b4, 0, st, g);
   else if (wide)
-    hipLaunchKernelGGL((npf::chain_kernel<32, 4, false, 0, 0>), dim3((unsigned)grid), b4, 0, st, g);
+    hipLaunchKernelGGL((npf::chain_kernel<32, 4, false, 0, 0, false>), dim3((unsigned)grid), b4, 0, st, g);
   else if (paired)
-    hipLaunchKernelGGL((npf::chain_kernel<16, 8, false, 16, 8>), dim3((unsigned)grid), b8, 0, st, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 8, false, 16, 8, false>), dim3((unsigned)grid), b8, 0, st, g);
   else if (n128 > n256)
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 8, 4>), dim3((unsigned)grid), b4, 0, st, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 8, 4, false>), dim3((unsigned)grid), b4, 0, st, g);
   else
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 16, 8>), dim3((unsigned)grid), b4, 0, st, g);
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 16, 8, false>), dim3((unsigned)grid), b4, 0, st, g);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

@@ -107,6 +107,27 @@ __global__ void gather_points_kernel(const float* __restrict__ x, const float* _
   }
 }
 
+// fp32 weights -> the bf16 image the bf16 chain instance streams: dst [rows][Kp] bf16 (Kp = roundup(cols, 32)),
+// columns permuted inside every group of 32 so that the 8 bf16 of lane group g are the features
+// {4g..4g+3} and {16+4g..16+4g+3} of the group -- the lane's own accumulator values of two adjacent
+// 16-row blocks, which is what v_mfma_f32_16x16x32_bf16 gets as its B operand.  transposed: dst rows
+// are the columns of src (the dgrad chains multiply by W^T).
+__global__ void cast_bf16_weights_kernel(const float* __restrict__ src, int n_rows, int n_cols, int ld, int transposed,
+                                         unsigned short* __restrict__ dst) {
+  const int rows = transposed ? n_cols : n_rows, cols = transposed ? n_rows : n_cols;
+  const int Kp = ((cols + 31) >> 5) * 32;
+  const size_t total = (size_t)rows * Kp;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = idx / Kp, q = idx - (size_t)r * Kp;
+    const int sgrp = q >> 5, g = (q & 31) >> 3, i = q & 7;
+    const int c = 32 * sgrp + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
+    float v = 0.f;
+    if (c < cols) v = transposed ? src[(size_t)c * ld + r] : src[(size_t)r * ld + c];
+    const __bf16 b = (__bf16)v;
+    dst[idx] = __builtin_bit_cast(unsigned short, b);
+  }
+}
+
 // 32x32 LDS tile transpose
 __global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
   __shared__ float tile[32][33];
@@ -220,6 +241,17 @@ extern "C" int npf_gather_points(const float* x, const float* y, const int64_t* 
   const size_t total = (size_t)n_tasks * n_sel;
   hipLaunchKernelGGL(npf::gather_points_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                      (const long long*)idx, n_tasks, n_points, n_sel, x_dim, y_dim, out_x, out_y);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_cast_bf16_weights(const float* src, int32_t n_rows, int32_t n_cols, int32_t ld, int32_t transposed,
+                                     void* dst, void* stream) {
+  if (!src || !dst || n_rows <= 0 || n_cols <= 0 || ld < n_cols || (((uintptr_t)dst) & 15)) return NPF_EINVAL;
+  const int rows = transposed ? n_cols : n_rows, cols = transposed ? n_rows : n_cols;
+  const size_t total = (size_t)rows * npf::round_up(cols, 32);
+  hipLaunchKernelGGL(npf::cast_bf16_weights_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     n_rows, n_cols, ld, transposed, (unsigned short*)dst);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

@@ -256,3 +256,56 @@ def test_split_merge_heads_roundtrip():
         assert torch.equal(FN.unpack_pt(sp, P, hs).cpu(), ref)
         back = FN.merge_heads(sp, B, P, F, H)
         assert torch.equal(FN.unpack_pt(back, P, F).cpu(), x)
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_bf16_linear_chain_matches_bf16_emulation():
+    """bf16 compute mode of the chain kernel (NPF_OP_LINEAR on npf_cast_bf16_weights images,
+    v_mfma_f32_16x16x32_bf16): every layer equals fp32-accumulated products of the bf16-rounded input
+    and bf16-rounded weights.  Widths that are / are not multiples of 32, skinny first and last layers."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(31)
+    for n_tasks, pts, dims in ((3, 70, (256, 256, 256)), (2, 45, (2, 64, 100, 36, 4)), (1, 33, (128, 128)), (2, 40, (32, 256, 32))):
+        x = torch.randn(n_tasks, pts, dims[0], generator=g)
+        Ws = [torch.randn(o, i, generator=g) / i ** 0.5 for i, o in zip(dims[:-1], dims[1:])]
+        bs = [torch.randn(o, generator=g) * 0.1 for o in dims[1:]]
+        ref = x.double()
+        for j, (W, b) in enumerate(zip(Ws, bs)):
+            ref = _bf16_round(ref.float()).double() @ _bf16_round(W).double().t() + b.double()
+            if j < len(Ws) - 1:
+                ref = torch.relu(ref)
+        prog = CH.Program(n_tasks, pts, False)
+        xp = FN.pack_pt(x.to(DEV))
+        out = CH.pt_empty(n_tasks, pts, dims[-1], DEV)
+        prog.load_pt(xp, dims[0])
+        for j, (W, b) in enumerate(zip(Ws, bs)):
+            prog.linear_bf16(CH.cast_bf16_weights(W.to(DEV)), W.shape[1], W.shape[0], bias=b.to(DEV), relu=j < len(Ws) - 1)
+        prog.store_pt(out, dims[-1])
+        prog.launch()
+        got = FN.unpack_pt(out, pts, dims[-1])
+        # the only difference to the emulation: fp32 (not fp64) accumulation, and a bf16 rounding that may
+        # flip when the fp32 intermediate sits next to a rounding boundary
+        assert_close(got, ref, tol=2e-3, what=f"bf16 chain {dims}")
+
+
+def test_bf16_weight_image_layout():
+    """npf_cast_bf16_weights: values rounded to nearest-even bf16, columns permuted inside groups of 32,
+    zero padding; transposed images."""
+    CH, _ = _mods()
+    g = torch.Generator().manual_seed(32)
+    W = torch.randn(37, 70, generator=g)
+    for transposed in (False, True):
+        M = W.t().contiguous() if transposed else W
+        img = CH.cast_bf16_weights(W.to(DEV), transposed=transposed).cpu().float()
+        rows, cols = M.shape
+        Kp = (cols + 31) // 32 * 32
+        assert img.shape == (rows, Kp)
+        ref = torch.zeros(rows, Kp)
+        ref[:, :cols] = M.to(torch.bfloat16).float()
+        q = torch.arange(Kp)
+        grp, gg, i = q // 32, (q % 32) // 8, q % 8
+        src = 32 * grp + torch.where(i < 4, 4 * gg + i, 16 + 4 * gg + (i - 4))
+        assert torch.equal(img, ref[:, src])
