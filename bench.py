@@ -221,10 +221,13 @@ def main():
     ap.add_argument("--trgt", type=int, default=None, help="target points per task (train: 1024, decode: 4096)")
     ap.add_argument("--r", type=int, default=None, help="feature width (train: 256, decode: 512)")
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = BASELINE config 2 (headline); bf16 = config 3's compute mode (bf16 MFMA in the MLP stacks, "
+                         "fp32 attention / accumulation / weight gradients), 1024 tasks per GPU by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
-    dflt = {"train": (256, 1024, 256), "decode": (512, 4096, 512)}[args.workload]
+    dflt = {"train": (1024 if args.dtype == "bf16" else 256, 1024, 256), "decode": (512, 4096, 512)}[args.workload]
     args.batch = dflt[0] if args.batch is None else args.batch
     args.trgt = dflt[1] if args.trgt is None else args.trgt
     args.r = dflt[2] if args.r is None else args.r
@@ -260,6 +263,10 @@ def main():
     from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
 
     B, C, T = args.batch, args.ctx, args.trgt
+    if args.dtype == "bf16":
+        import npf_gwwaveform_amd as A
+
+        A.set_compute_dtype("bf16")
     model, crit = build_model(args.model, args.r, args.layers, dev)
     n_params = sum(p.numel() for p in model.parameters())
     trainer = Trainer(model, crit, lr=1e-3, world=world)
@@ -318,6 +325,8 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         name, (n, fl, sec, nb) = dom
         ach = fl / sec * 1e-12
+        # (in the bf16 mode the chain launches mix bf16 MLP layers and fp32 attention: they are priced
+        # against the fp32 peak too, i.e. frac can exceed what an all-fp32 kernel could reach)
         roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
         # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
@@ -327,7 +336,7 @@ def main():
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
             try:
                 k = json.load(open(f))["kernels"].get("npf::" + name)
-                if k and "hbm_bytes_per_launch" in k and (args.batch, C, T, args.r) == (256, 256, 1024, 256):
+                if k and "hbm_bytes_per_launch" in k and (args.batch, C, T, args.r, args.dtype) == (256, 256, 1024, 256, "fp32"):
                     roofline["traffic"] = k["hbm_bytes_per_launch"]
                     roofline["traffic_unit"] = "bytes/launch"
                     roofline["traffic_source"] = os.path.relpath(f, ROOT)
@@ -352,12 +361,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 (MLP-stack MFMAs; attention, accumulation, weight gradients f32)",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
-                "workload": f"BASELINE config 2: {'AttnCNP' if args.model == 'attncnp' else 'AttnLNP(is_q_zCct, n_z=1)'} "
+                "workload": f"BASELINE config {2 if args.dtype == 'fp32' else 3}: {'AttnCNP' if args.model == 'attncnp' else 'AttnLNP(is_q_zCct, n_z=1)'} "
                             f"scaledot, r={args.r}, {args.layers}-layer xy-encoder/decoder, {C} context / {T} target "
-                            f"points, {B} tasks per GPU, fp32 train step (fwd+loss+bwd+allreduce+Adam)",
+                            f"points, {B} tasks per GPU, {args.dtype} train step (fwd+loss+bwd+allreduce+Adam)",
                 "tasks_per_gpu": B, "global_tasks": B * world, "context_points": C, "target_points": T,
                 "r_dim": args.r, "n_params": n_params, "parallelism": f"dp{world}", "final_loss": loss_val,
                 "train_step_tflops_algorithmic": (value * flop_pt * 1e-12) if flop_pt else None,

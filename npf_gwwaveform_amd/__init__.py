@@ -6,6 +6,7 @@ The compute runs in hand-written HIP kernels (``csrc/``) reached through a C ABI
 """
 from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, SelfAttention, TransformerAttender, get_attender,
                             merge_flat_input)
+from .chain import set_compute_dtype
 from .datasplit import CntxtTrgtGetter, GetRandomIndcs, GetRangeIndcs, get_all_indcs
 from .losses import CNPFLoss, ELBOLossLNPF, LightTailPareto, NLLLossLNPF, SUMOLossLNPF
 from .neuralproc import (CNP, LNP, AttnCNP, AttnLNP, LatentNeuralProcessFamily, MultivariateNormalDiag,
@@ -36,5 +37,5 @@ __all__ = [
     "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "SelfAttention", "get_attender",
     "NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP", "NPFModel",
     "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "SUMOLossLNPF", "LightTailPareto", "MultivariateNormalDiag", "encode", "aggregate", "decode",
-    "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs",
+    "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs", "set_compute_dtype",
 ]

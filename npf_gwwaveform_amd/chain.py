@@ -30,6 +30,37 @@ DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microben
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 
 
+# Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
+# of shared-weight Linear layers and elementwise steps multiplies in bf16 (weights and layer inputs rounded
+# to bf16 at the MFMA, fp32 accumulation / bias / activations in HBM / weight gradients); attention,
+# LayerNorm and row-major inference inputs stay on the fp32 instances.
+COMPUTE_DTYPE = "fp32"
+_BF16_STEPS = {"input_pt", "input_rows", "linear", "add_pt", "add_taskvec", "tap", "output_pt", "output_rows", "store_tr"}
+_IMG_CACHE: dict = {}
+
+
+def set_compute_dtype(dtype: str) -> None:
+    """"fp32" (default, the parity-gated path) or "bf16" (BASELINE config 3)."""
+    global COMPUTE_DTYPE
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(f"unknown compute dtype {dtype!r}")
+    COMPUTE_DTYPE = dtype
+
+
+def _bf16_image(W: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """Cached ``cast_bf16_weights`` image of a weight tensor, re-cast when the tensor was modified
+    (optimizer step)."""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
+    hit = _IMG_CACHE.get(key)
+    if hit is not None and hit[0] == W._version:
+        return hit[1]
+    if len(_IMG_CACHE) > 512:
+        _IMG_CACHE.clear()
+    img = cast_bf16_weights(W, transposed=transposed)
+    _IMG_CACHE[key] = (W._version, img)
+    return img
+
+
 def pad32(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -429,6 +460,9 @@ class _ChainFn(torch.autograd.Function):
         dev = chain.device
         T = [t.detach() if t is not None else None for t in chain.tensors]
         ctx_tiles = lambda k: T[k].shape[1]  # noqa: E731
+        bf16 = (COMPUTE_DTYPE == "bf16" and all(st.kind in _BF16_STEPS for st in chain.steps)
+                and not any(st.kind == "linear" and st.a.get("add_rm") for st in chain.steps)
+                and max([max(st.a["N"], st.a["K"]) for st in chain.steps if st.kind == "linear"], default=0) <= 256)
 
         saved = {}      # (step index, role) -> PT tensor
         outputs = []
@@ -467,9 +501,14 @@ class _ChainFn(torch.autograd.Function):
                     saved[(i, "in")] = ensure_saved(a["K"])
                 if a.get("add_rm") and train and (upstream or needs_grad[W] or needs_grad[add]):
                     raise NotImplementedError("row-major addends carry no gradient (inference path)")
-                prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
-                            addend=T[add] if add >= 0 else None, addend_modulus=a["mod"], ldw=T[W].stride(0),
-                            b_task_stride=(T[b].stride(0) if a["bpt"] else 0), addend_rm=bool(a.get("add_rm")))
+                if bf16:
+                    prog.linear_bf16(_bf16_image(T[W], False), a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
+                                     addend=T[add] if add >= 0 else None, addend_modulus=a["mod"],
+                                     b_task_stride=(T[b].stride(0) if a["bpt"] else 0))
+                else:
+                    prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
+                                addend=T[add] if add >= 0 else None, addend_modulus=a["mod"], ldw=T[W].stride(0),
+                                b_task_stride=(T[b].stride(0) if a["bpt"] else 0), addend_rm=bool(a.get("add_rm")))
                 backed = None
                 upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if train and a["relu"] and upstream:
@@ -534,6 +573,7 @@ class _ChainFn(torch.autograd.Function):
                 raise AssertionError(k)
         prog.launch()
         ctx.chain, ctx.saved, ctx.T, ctx.needs_grad, ctx.upstream_before = chain, saved, T, needs_grad, upstream_before
+        ctx.bf16 = bf16
         ctx.train = train
         if non_diff:
             ctx.mark_non_differentiable(*non_diff)
@@ -608,8 +648,11 @@ class _ChainFn(torch.autograd.Function):
                     if add >= 0 and needs_grad[add]:
                         grads[add] = (dz, a["mod"])  # resolved after the launch
                 if upstream_before[i]:
-                    Wt = transpose(T[W])  # [K, N]
-                    prog.linear(Wt, a["N"], a["K"])
+                    if ctx.bf16:
+                        prog.linear_bf16(_bf16_image(T[W], True), a["N"], a["K"])
+                    else:
+                        Wt = transpose(T[W])  # [K, N]
+                        prog.linear(Wt, a["N"], a["K"])
                 else:
                     started = False  # nothing upstream needs this gradient
                     break

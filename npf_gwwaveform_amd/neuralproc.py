@@ -433,8 +433,13 @@ class AttnCNP(NeuralProcessFamily):
         """cur of ``ch`` <- attention of the targets over the context (attnnp.py:118-131): fused into
         the chain while a score row fits the registers, blocked (attention_long.py) beyond that."""
         k_tr, v_tr = getattr(Xc_pt, "_npf_tr", None), getattr(R, "_npf_tr", None)
+        from . import chain as _chain
+
         if not isinstance(self.attender, DotAttender):  # learned projections: its own launches
             ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T), self.r_dim)
+        elif _chain.COMPUTE_DTYPE == "bf16":
+            # bf16 compute mode: the attention keeps its fp32 launch, the decoder chain behind it is bf16
+            ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T, keys_tr=k_tr, values_tr=v_tr), self.r_dim)
         elif self.attender.fits_fused(C):
             ch.input_pt(Xt_pt, self.x_transf_dim)
             self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr)
