@@ -150,8 +150,11 @@ typedef struct npf_wgrad_job {
   int64_t ldw;      /* row stride of dW in floats (per_task == 0) */
   int32_t N, K;
   int32_t per_task;
-  int32_t accumulate; /* 0: overwrite dW/db, 1: add to them */
+  int32_t accumulate; /* bit 0: 0 = overwrite dW/db, 1 = add to them; bit 1 (NPF_WGRAD_BF16): round the
+                         operands to bf16 at the MFMA input (bf16 compute mode; all jobs of a launch alike) */
 } npf_wgrad_job_t;
+#define NPF_WGRAD_ACCUMULATE 1
+#define NPF_WGRAD_BF16 2
 
 #define NPF_MAX_WGRAD_JOBS 16
 /* Runs up to NPF_MAX_WGRAD_JOBS jobs over the same points in ONE launch (+ one reduce). */

@@ -32,8 +32,9 @@ FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
 # of shared-weight Linear layers and elementwise steps multiplies in bf16 (weights and layer inputs rounded
-# to bf16 at the MFMA, fp32 accumulation / bias / activations in HBM / weight gradients); attention,
-# LayerNorm and row-major inference inputs stay on the fp32 instances.
+# to bf16 at the MFMA, fp32 accumulation / bias / activations in HBM) and every weight / key / value
+# gradient is a bf16-product contraction; attention chains, LayerNorm and row-major inference inputs stay
+# on the fp32 instances.
 COMPUTE_DTYPE = "fp32"
 _BF16_STEPS = {"input_pt", "input_rows", "linear", "add_pt", "add_taskvec", "tap", "output_pt", "output_rows", "store_tr"}
 _IMG_CACHE: dict = {}
@@ -269,7 +270,8 @@ def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
             arr[j].ldw = jb.get("ldw") or jb["K"]
             arr[j].N, arr[j].K = jb["N"], jb["K"]
             arr[j].per_task = int(jb.get("per_task", False))
-            arr[j].accumulate = int(jb.get("accumulate", False))
+            # bit 1: bf16 products (bf16 compute mode: every weight / key / value gradient of the step)
+            arr[j].accumulate = int(jb.get("accumulate", False)) | (2 if COMPUTE_DTYPE == "bf16" else 0)
         nbytes = lib.npf_wgrad_partials_bytes(arr, len(chunk), n_tasks, tiles_of(pts))
         if nbytes < 0:
             raise RuntimeError("npf_wgrad_partials_bytes: invalid wgrad jobs")

@@ -42,6 +42,22 @@ __device__ __forceinline__ void wg_dma16(const float* src, float* lds_dst_wave_u
 // dense (512 B per row), chunk c of row r stored at chunk position c ^ (r & 15): the fragment
 // read (16 quad rows x 4 consecutive points per ds_read_b128) is then bank-conflict free and
 // a 1 KiB LDS-DMA piece (2 rows) lands linearly with the swizzle applied to its source address.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x4 pack4_bf16(float a, float b, float c, float d) {
+  const bf16x2v lo = __builtin_convertvector((f32x2v{a, b}), bf16x2v), hi = __builtin_convertvector((f32x2v{c, d}), bf16x2v);
+  bf16x4 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+  return r;
+}
+
+// BF16: the same contraction with the operands rounded to bf16 at the MFMA input
+// (v_mfma_f32_16x16x16_bf16, fp32 accumulation): the k-slots of a lane group are 4 consecutive points, so
+// a lane reads its quad row at 4 points (4 x ds_read_b128 per operand) and forms the 4 + 4 operands of
+// the 16 (m, m') MFMAs of a 16-point step; 2 steps per tile instead of 8 -- the kernel becomes HBM-bound.
+template <bool BF16>
 __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J, float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kQRows * 128];  // 2 buffers x (dZ, A)
   constexpr int kOp = kQRows * 128;  // floats per operand image
@@ -122,7 +138,33 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
     __syncthreads();  // vmcnt(0): tile t has landed; everyone is done with the other buffer
     if (t + 1 < t1) tile_dma(t + 1, lds + (cur ^ 1) * 2 * kOp);
     const unsigned boff = cur * 2 * kOp * 4;
-    if (act) {
+    if constexpr (BF16) {
+      if (act) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          // points 16 t2 + 4 g + j, j < 4: chunk c of quad row r lives at chunk position c ^ (r & 15)
+          f32x4 qa[4], qb[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int c = 16 * t2 + 4 * g + jj;
+            qa[jj] = *(const f32x4*)(lds + cur * 2 * kOp + (16 * rg + i) * 128 + ((c ^ i) << 2));
+            qb[jj] = *(const f32x4*)(lds + cur * 2 * kOp + kOp + (16 * cg + i) * 128 + ((c ^ i) << 2));
+          }
+          if (cg == 0) dbacc += (qa[0] + qa[1]) + (qa[2] + qa[3]);
+          bf16x4 am[4], bn[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            am[m] = pack4_bf16(qa[0][m], qa[1][m], qa[2][m], qa[3][m]);
+            bn[m] = pack4_bf16(qb[0][m], qb[1][m], qb[2][m], qb[3][m]);
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2)
+              acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(am[m], bn[n2], acc[m][n2], 0, 0, 0);
+        }
+      }
+    } else if (act) {
       // 8 steps of 4 points; the fragments of step s+1 are read (inline asm, pinned) before the 16
       // MFMAs of step s issue: hipcc otherwise reads them right before use and exposes the LDS
       // latency 8 times per tile
@@ -167,7 +209,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 #pragma unroll
             for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
             float* dst = out + ((size_t)(row >> 5) * (Kp >> 2) + (col >> 2)) * 128 + (row & 31) * 4;
-            if (job.accumulate) v += *(const f32x4*)dst;
+            if (job.accumulate & NPF_WGRAD_ACCUMULATE) v += *(const f32x4*)dst;
             *(f32x4*)dst = v;
           }
         }
@@ -229,13 +271,13 @@ __global__ void wgrad_reduce_kernel(const WgradJobs J, const float* __restrict__
         float* d = job.dW + (size_t)n * job.ldw + k;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (k + e < job.K) d[e] = job.accumulate ? d[e] + s[e] : s[e];
+          if (k + e < job.K) d[e] = (job.accumulate & NPF_WGRAD_ACCUMULATE) ? d[e] + s[e] : s[e];
       }
     } else if (job.db) {
       const int n = idx - Np * Kp;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (n + e < job.N) job.db[n + e] = job.accumulate ? job.db[n + e] + s[e] : s[e];
+        if (n + e < job.N) job.db[n + e] = (job.accumulate & NPF_WGRAD_ACCUMULATE) ? job.db[n + e] + s[e] : s[e];
     }
   }
 }
@@ -313,7 +355,12 @@ extern "C" int npf_wgrad_run(const npf_wgrad_job_t* jobs, int32_t n_jobs, int32_
   for (int j = 0; j < n_jobs; ++j) any_shared |= !jobs[j].per_task;
   if (any_shared && (!partials || partials_bytes < need || (((uintptr_t)partials) & 15))) return NPF_EINVAL;
   const int n_wg = J.first_wg[n_jobs];
-  hipLaunchKernelGGL(npf::wgrad_kernel, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);
+  bool bf16 = true;
+  for (int j = 0; j < n_jobs; ++j) bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
+  if (bf16)
+    hipLaunchKernelGGL(npf::wgrad_kernel<true>, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);
+  else
+    hipLaunchKernelGGL(npf::wgrad_kernel<false>, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);
   NPF_CHECK_LAUNCH();
   if (any_shared) {
     hipLaunchKernelGGL(npf::wgrad_reduce_kernel, dim3(65, n_jobs), dim3(256), 0, (hipStream_t)stream, J,

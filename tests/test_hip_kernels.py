@@ -309,3 +309,22 @@ def test_bf16_weight_image_layout():
         grp, gg, i = q // 32, (q % 32) // 8, q % 8
         src = 32 * grp + torch.where(i < 4, 4 * gg + i, 16 + 4 * gg + (i - 4))
         assert torch.equal(img, ref[:, src])
+
+
+def test_bf16_wgrad_matches_bf16_emulation():
+    """wgrad kernel in the bf16 compute mode (NPF_WGRAD_BF16, v_mfma_f32_16x16x16_bf16): dW and db equal the
+    contraction of the bf16-rounded operands (fp32 accumulation; db sums the unrounded dZ)."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(41)
+    for n_tasks, pts, N, K in ((3, 70, 256, 256), (2, 45, 100, 36), (1, 200, 32, 256), (4, 33, 64, 2)):
+        dz, a = torch.randn(n_tasks, pts, N, generator=g), torch.randn(n_tasks, pts, K, generator=g)
+        ref = torch.einsum("bpn,bpk->nk", _bf16_round(dz).double(), _bf16_round(a).double())
+        dW = torch.empty(N, K, device=DEV)
+        db = torch.empty(N, device=DEV)
+        CH.COMPUTE_DTYPE = "bf16"
+        try:
+            CH.run_wgrad([dict(dZ=FN.pack_pt(dz.to(DEV)), A=FN.pack_pt(a.to(DEV)), N=N, K=K, dW=dW, db=db)], n_tasks, pts, DEV)
+        finally:
+            CH.COMPUTE_DTYPE = "fp32"
+        assert_close(dW, ref, tol=1e-4, what=f"bf16 wgrad {N}x{K}")
+        assert_close(db, dz.double().sum((0, 1)), tol=1e-5, what="bf16 wgrad db")
