@@ -80,6 +80,11 @@ enum npf_opcode {
                               features of the point (nn.LayerNorm of TransformerAttender,
                               npf/architectures/attention.py:552-553,583-586); p0 (gamma), p1
                               (beta): 16-byte aligned, zero-padded to a multiple of 32 floats    */
+  NPF_OP_STORE_WB = 18,    /* bf16 mode only: p0 [task][i1 >= 32*tiles rows][roundup(i0, 32)] bf16 <- cur, one row per
+                              point, features k-permuted like npf_cast_bf16_weights: the activations as a
+                              bf16 weight image W[n = point][k = feature] (per-task NPF_W_ROWMAJOR)         */
+  NPF_OP_STORE_TRB = 19,   /* bf16 mode only: p0 [task][i0 features][i1 = 32*tiles columns] bf16 <- cur, the
+                              transposed image W[n = feature][k = point], points k-permuted in groups of 32  */
   NPF_OP_LOAD_RM = 17,     /* cur <- row-major p0 [task][pt][i0], i0 % 32 == 0, i0 <= 512 (i4 = modulus)  */
   NPF_OP_LAYERNORM_BWD = 16 /* cur = dy on entry; x = PT32 p0 (the forward input, i0 = F), gamma p1:
                               xhat = (x - mean) rstd;  PT32 p2 <- dy * xhat (for dgamma);

@@ -159,12 +159,19 @@ class MergeFlatInputs(nn.Module):
         (with ``_npf_tr`` set to the feature-major copy when ``with_tr``).  One launch for an MLP flat
         module; for a SelfAttention flat module the merge is a launch and the attention layers follow."""
         if isinstance(self.flat_module, MLP):
+            from . import chain as _chain
+
             self.append_to(ch, x1_pt=x1_pt, **kw).output_pt()
+            imgs = with_tr and _chain.COMPUTE_DTYPE == "bf16"
             if with_tr:
                 ch.store_tr()
+            if imgs:
+                ch.store_bf16_images()
             outs = ch.run()
             if with_tr:
                 outs[0]._npf_tr = outs[1]
+            if imgs:
+                outs[0]._npf_img = (outs[2], outs[3])
             return outs[0]
         rl = self.resizer.layers()
         for lin in rl[:-1]:
@@ -235,12 +242,14 @@ class DotAttender(nn.Module):
         self.is_normalize, self.is_resize = True, False
         self.dropout = nn.Identity()
 
-    def append_to(self, ch: Chain, keys_pt, values_pt, n_keys: int, keys_tr=None, values_tr=None) -> Chain:
+    def append_to(self, ch: Chain, keys_pt, values_pt, n_keys: int, keys_tr=None, values_tr=None, keys_img=None,
+                  values_img=None) -> Chain:
         """cur = queries on entry, context vectors on exit.  ``keys_tr`` / ``values_tr``:
-        feature-major copies of the keys / values (``Chain.store_tr``) for the DMA fast path."""
+        feature-major copies of the keys / values (``Chain.store_tr``) for the DMA fast path;
+        ``keys_img`` / ``values_img``: their bf16 images (``Chain.store_bf16_images``, bf16 mode)."""
         scale = 1.0 / math.sqrt(self.kq_size) if self.is_scale else 1.0
-        return (ch.attn_scores(keys_pt, n_keys, keys_tr=keys_tr).softmax(scale)
-                .attn_values(values_pt, self.value_size, values_tr=values_tr))
+        return (ch.attn_scores(keys_pt, n_keys, keys_tr=keys_tr, keys_img=keys_img).softmax(scale)
+                .attn_values(values_pt, self.value_size, values_tr=values_tr, values_img=values_img))
 
     def fits_fused(self, n_keys: int) -> bool:
         """Can ``append_to`` keep a whole score row in registers (else: ``attend_pt``)."""

@@ -36,7 +36,9 @@ FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 # gradient is a bf16-product contraction; attention chains, LayerNorm and row-major inference inputs stay
 # on the fp32 instances.
 COMPUTE_DTYPE = "fp32"
-_BF16_STEPS = {"input_pt", "input_rows", "linear", "add_pt", "add_taskvec", "tap", "output_pt", "output_rows", "store_tr"}
+_BF16_STEPS = {"input_pt", "input_rows", "linear", "add_pt", "add_taskvec", "tap", "output_pt", "output_rows", "store_tr",
+               "store_wb", "store_trb", "softmax"}
+_BF16_ATTN_STEPS = {"attn_scores", "attn_values"}  # eligible when the chain was given bf16 images of keys / values
 _IMG_CACHE: dict = {}
 
 
@@ -177,17 +179,35 @@ class Program:
         self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=mode, i3=i3, flags=flags, i4=addend_modulus, p0=L.ptr(W, strided=True),
                  p1=self._p(bias), p2=self._p(addend), s0=w_task_stride, s1=b_task_stride)
 
-    def linear_bf16(self, W_img, K, N, bias=None, relu=False, addend=None, addend_modulus=0, b_task_stride=0):
-        """LINEAR in the bf16 compute mode: ``W_img`` = ``cast_bf16_weights`` image [N, pad32(K)] (bf16)."""
+    def linear_bf16(self, W_img, K, N, bias=None, relu=False, addend=None, addend_modulus=0, b_task_stride=0,
+                    per_task=False):
+        """LINEAR in the bf16 compute mode: ``W_img`` = ``cast_bf16_weights`` image [N, pad32(K)] (bf16), or with
+        ``per_task`` a ``store_wb`` / ``store_trb`` image [n_tasks, rows >= N, pad32(K)] of activations."""
         if self.ops and not self.bf16 and any(o.op == L.OP_LINEAR for o in self.ops):
             raise ValueError("a program is either all-fp32 or all-bf16")
-        if W_img.dtype != torch.bfloat16 or tuple(W_img.shape) != (N, pad32(K)) or not W_img.is_contiguous():
-            raise ValueError(f"bf16 weight image must be contiguous [N, pad32(K)] bfloat16, got {tuple(W_img.shape)} {W_img.dtype}")
+        ok = W_img.dtype == torch.bfloat16 and W_img.is_contiguous() and W_img.shape[-1] == pad32(K)
+        ok = ok and ((W_img.dim() == 3 and W_img.shape[0] == self.n_tasks and W_img.shape[1] >= N) if per_task
+                     else tuple(W_img.shape) == (N, pad32(K)))
+        if not ok:
+            raise ValueError(f"bad bf16 weight image {tuple(W_img.shape)} {W_img.dtype} for a {K}->{N} layer")
         self.bf16 = True
         flags = (L.F_RELU if relu else 0) | (L.F_ADD_PT if addend is not None else 0)
         self.keep.append(W_img)
         self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=L.W_ROWMAJOR, i3=pad32(K) // 2, flags=flags, i4=addend_modulus,
-                 p0=W_img.data_ptr(), p1=self._p(bias), p2=self._p(addend), s0=0, s1=b_task_stride)
+                 p0=W_img.data_ptr(), p1=self._p(bias), p2=self._p(addend),
+                 s0=(W_img.shape[1] * pad32(K) // 2 if per_task else 0), s1=b_task_stride)
+
+    def store_wb(self, img, F):
+        """bf16 row image [n_tasks, 32*tiles, pad32(F)] <- cur (bf16 mode)."""
+        self.bf16 = True
+        self.keep.append(img)
+        self._op(op=L.OP_STORE_WB, i0=F, i1=img.shape[1], p0=img.data_ptr())
+
+    def store_trb(self, img, F):
+        """bf16 transposed image [n_tasks, F, 32*tiles] <- cur (bf16 mode)."""
+        self.bf16 = True
+        self.keep.append(img)
+        self._op(op=L.OP_STORE_TRB, i0=F, i1=img.shape[2], p0=img.data_ptr())
 
     def flops(self) -> int:
         """Algorithmic GEMM FLOPs of one launch: 2*K*N per LINEAR per valid point."""
@@ -206,6 +226,8 @@ class Program:
                 per_pt += 4 * o.i0
             elif o.op in (L.OP_LOAD_ROWS, L.OP_STORE_ROWS, L.OP_STORE_TR):
                 per_pt += 4 * o.i0
+            elif o.op in (L.OP_STORE_WB, L.OP_STORE_TRB):
+                per_pt += 2 * pad32(o.i0)
             elif o.op == L.OP_SOFTMAX and o.i1:
                 per_pt += 8
             elif o.op == L.OP_LAYERNORM_BWD:
@@ -393,7 +415,16 @@ class Chain:
         self.steps.append(_Step("layernorm", {"g": self._t(weight), "b": self._t(bias)}, {"F": self.F, "eps": float(eps)}))
         return self
 
-    def attn_scores(self, keys_pt: torch.Tensor, n_keys: int, keys_tr: Optional[torch.Tensor] = None) -> "Chain":
+    def store_bf16_images(self) -> "Chain":
+        """Two extra (non-differentiable) outputs, bf16 compute mode only: cur as a bf16 row image
+        [n_tasks, 32*tiles, pad32(F)] and as a transposed image [n_tasks, F, 32*tiles] -- what an attention
+        chain takes as ``keys_img`` / ``values_img``."""
+        self.steps.append(_Step("store_wb", {}, {"F": self.F}))
+        self.steps.append(_Step("store_trb", {}, {"F": self.F}))
+        return self
+
+    def attn_scores(self, keys_pt: torch.Tensor, n_keys: int, keys_tr: Optional[torch.Tensor] = None,
+                    keys_img=None) -> "Chain":
         """cur[c] <- sum_d keys[c][d] cur[d] (DotAttender.score, attention.py:204-220, unscaled).
         ``keys_tr``: optional feature-major copy [n_tasks, d, 32*tiles] of the keys (``store_tr``):
         lets the backward pass stream K^T by LDS-DMA."""
@@ -403,7 +434,8 @@ class Chain:
             raise NotImplementedError(
                 f"a fused score row holds at most {L.NPF_MAX_TRAIN_FEATURES} context points; longer contexts go "
                 "through DotAttender.attend_pt (attention_long.py)")
-        self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F, "tr": keys_tr}))
+        self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F, "tr": keys_tr,
+                                                                          "img": keys_img}))
         self.F = n_keys
         return self
 
@@ -411,10 +443,12 @@ class Chain:
         self.steps.append(_Step("softmax", {}, {"n": self.F, "scale": float(scale)}))
         return self
 
-    def attn_values(self, values_pt: torch.Tensor, r: int, values_tr: Optional[torch.Tensor] = None) -> "Chain":
+    def attn_values(self, values_pt: torch.Tensor, r: int, values_tr: Optional[torch.Tensor] = None,
+                    values_img=None) -> "Chain":
         """cur[n] <- sum_c values[c][n] cur[c] (torch.bmm(attn, values), attention.py:151).
         ``values_tr``: optional feature-major copy [n_tasks, r, 32*tiles] of the values."""
-        self.steps.append(_Step("attn_values", {"v": self._t(values_pt)}, {"C": self.F, "r": r, "tr": values_tr}))
+        self.steps.append(_Step("attn_values", {"v": self._t(values_pt)}, {"C": self.F, "r": r, "tr": values_tr,
+                                                                            "img": values_img}))
         self.F = r
         return self
 
@@ -462,7 +496,9 @@ class _ChainFn(torch.autograd.Function):
         dev = chain.device
         T = [t.detach() if t is not None else None for t in chain.tensors]
         ctx_tiles = lambda k: T[k].shape[1]  # noqa: E731
-        bf16 = (COMPUTE_DTYPE == "bf16" and all(st.kind in _BF16_STEPS for st in chain.steps)
+        bf16 = (COMPUTE_DTYPE == "bf16"
+                and all(st.kind in _BF16_STEPS or (st.kind in _BF16_ATTN_STEPS and st.a.get("img") is not None)
+                        for st in chain.steps)
                 and not any(st.kind == "linear" and st.a.get("add_rm") for st in chain.steps)
                 and max([max(st.a["N"], st.a["K"]) for st in chain.steps if st.kind == "linear"], default=0) <= 256)
 
@@ -538,7 +574,10 @@ class _ChainFn(torch.autograd.Function):
                 kk = st.t["k"]
                 if train and needs_grad[kk]:
                     saved[(i, "in")] = ensure_saved(a["r"])
-                prog.linear(T[kk], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=ctx_tiles(kk))
+                if bf16:
+                    prog.linear_bf16(a["img"][0], a["r"], a["C"], per_task=True)
+                else:
+                    prog.linear(T[kk], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=ctx_tiles(kk))
                 backed = None
                 upstream = upstream or needs_grad[kk]
             elif k == "softmax":
@@ -550,7 +589,9 @@ class _ChainFn(torch.autograd.Function):
                 vv = st.t["v"]
                 if train and needs_grad[vv]:
                     saved[(i, "in")] = ensure_saved(a["C"])
-                if a["tr"] is not None:
+                if bf16:
+                    prog.linear_bf16(a["img"][1], a["C"], a["r"], per_task=True)
+                elif a["tr"] is not None:
                     ld = a["tr"].shape[2]
                     prog.linear(a["tr"], a["C"], a["r"], mode=L.W_ROWMAJOR, ldw=ld, w_task_stride=a["r"] * ld)
                 else:
@@ -560,6 +601,15 @@ class _ChainFn(torch.autograd.Function):
             elif k == "store_tr":
                 o = torch.empty((chain.n_tasks, a["F"], 32 * tiles_of(chain.pts)), dtype=torch.float32, device=dev)
                 prog.store_tr(o, a["F"], o.shape[2])
+                outputs.append(o)
+                non_diff.append(o)
+            elif k in ("store_wb", "store_trb"):
+                if not bf16:
+                    raise RuntimeError("bf16 images exist in the bf16 compute mode only")
+                cols = 32 * tiles_of(chain.pts)
+                shape = (chain.n_tasks, cols, pad32(a["F"])) if k == "store_wb" else (chain.n_tasks, a["F"], cols)
+                o = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+                (prog.store_wb if k == "store_wb" else prog.store_trb)(o, a["F"])
                 outputs.append(o)
                 non_diff.append(o)
             elif k in ("tap", "output_pt"):
@@ -606,12 +656,12 @@ class _ChainFn(torch.autograd.Function):
                 return buf.view(chain.n_tasks // mod, mod, *buf.shape[1:]).sum(0)
             return buf
 
-        n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows", "store_tr"))
+        n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows", "store_tr", "store_wb", "store_trb"))
         assert len(gouts) == n_out
         for i in range(len(chain.steps) - 1, -1, -1):
             st = chain.steps[i]
             k, a = st.kind, st.a
-            if k == "store_tr":
+            if k in ("store_tr", "store_wb", "store_trb"):
                 gouts.pop()
                 continue
             if k in ("output_pt", "output_rows", "tap"):
@@ -688,7 +738,10 @@ class _ChainFn(torch.autograd.Function):
                     dV = torch.empty_like(T[vv])
                     jobs.append(dict(dZ=saved[(i, "in")], A=dO, N=a["C"], K=a["r"], dW=dV, per_task=True))
                     grads[vv] = dV
-                prog.linear(T[vv], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=T[vv].shape[1])
+                if ctx.bf16:
+                    prog.linear_bf16(a["img"][0], a["r"], a["C"], per_task=True)   # dP = dO V^T (row image of the values)
+                else:
+                    prog.linear(T[vv], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=T[vv].shape[1])
             elif k == "softmax":
                 P = saved[(i, "out")]
                 prog.rowdot_pt(P, a["n"])
@@ -702,7 +755,9 @@ class _ChainFn(torch.autograd.Function):
                     jobs.append(dict(dZ=dS, A=saved[(i, "in")], N=a["C"], K=a["r"], dW=dK, per_task=True))
                     grads[kk] = dK
                 if upstream_before[i]:
-                    if a["tr"] is not None:
+                    if ctx.bf16:
+                        prog.linear_bf16(a["img"][1], a["C"], a["r"], per_task=True)  # dQ = dS K (transposed image of the keys)
+                    elif a["tr"] is not None:
                         ld = a["tr"].shape[2]
                         prog.linear(a["tr"], a["C"], a["r"], mode=L.W_ROWMAJOR, ldw=ld, w_task_stride=a["r"] * ld)
                     else:

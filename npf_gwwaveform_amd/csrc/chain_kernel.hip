@@ -845,6 +845,34 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
             if (f < F) dst[(size_t)f * ld] = cur[b][e];
           }
       }
+    } else if (opc == NPF_OP_STORE_WB || opc == NPF_OP_STORE_TRB) {
+      if constexpr (BF16) {
+        const int F = o.i0, ld = o.i1, Fp = ((F + 31) >> 5) * 32;
+        if (opc == NPF_OP_STORE_WB) {
+          // row image: this lane's 8 values of the feature group s (blocks 2s, 2s+1) are 16 contiguous bytes
+          unsigned short* dst = (unsigned short*)o.p0 + ((size_t)w.task * ld + pt) * Fp + 8 * w.g;
+          if (w.valid) {
+#pragma unroll
+            for (int st = 0; st < kMaxB16 / 2; ++st)
+              if (32 * st < Fp) *(bf16x8*)(dst + 32 * st) = pack_bf16(cur[2 * st], cur[2 * st + 1]);
+          }
+        } else {
+          // transposed image: point p = 32 t + r sits at column 32 t + 8 ((r & 15) >> 2) + 4 (r >> 4) + (r & 3)
+          const int r = pt & 31;
+          const int col = (pt & ~31) + 8 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3);
+          unsigned short* dst = (unsigned short*)o.p0 + (size_t)w.task * F * ld + col;
+          if (w.valid) {
+#pragma unroll
+            for (int b = 0; b < kMaxB16; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int f = 16 * b + 4 * w.g + e;
+                const __bf16 v = (__bf16)cur[b][e];
+                if (f < F) dst[(size_t)f * ld] = __builtin_bit_cast(unsigned short, v);
+              }
+          }
+        }
+      }
     } else if (opc == NPF_OP_LOAD_ROWS) {
       const int kd = o.i0;
       const float* src = (const float*)o.p0 + ((size_t)eff_task(w, o.i4) * g.pts_per_task + pt) * kd;
@@ -1060,6 +1088,12 @@ static int validate(const npf_program_t* g) {
       case NPF_OP_STORE_TR:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || !o.p0 || o.i1 < g->tiles_per_task * 32) return NPF_EINVAL;
         break;
+      case NPF_OP_STORE_WB:
+      case NPF_OP_STORE_TRB:
+        if (g->reserved[2] != 1 || o.i0 <= 0 || o.i0 > 256 || !o.p0 || (((uintptr_t)o.p0) & 15) ||
+            o.i1 < g->tiles_per_task * 32 || (o.i1 & 31))
+          return NPF_EINVAL;
+        break;
       case NPF_OP_LAYERNORM:
         if (o.i0 <= 0 || o.i0 > 256 || !o.p0 || !o.p1 || ((((uintptr_t)o.p0) | ((uintptr_t)o.p1)) & 15) || !(o.f0 > 0.f))
           return NPF_EINVAL;
@@ -1130,7 +1164,8 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
     if (extra || wide) return NPF_EINVAL;
     for (int i = 0; i < g.n_ops; ++i) {
       const npf_op_t& o = g.ops[i];
-      if (o.op == NPF_OP_LINEAR && (o.i2 != NPF_W_ROWMAJOR || (((uintptr_t)o.p0) & 15) || o.i3 < ((o.i0 + 31) >> 5) * 16))
+      if (o.op == NPF_OP_LINEAR && (o.i2 != NPF_W_ROWMAJOR || (((uintptr_t)o.p0) & 15) || o.i3 < ((o.i0 + 31) >> 5) * 16 ||
+                                    (o.s0 & 3)))
         return NPF_EINVAL;
     }
     hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 0, 0, true>), dim3((unsigned)grid_for(2)), dim3(256), 0,

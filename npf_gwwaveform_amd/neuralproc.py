@@ -145,12 +145,19 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         B, P, dx = X.shape
         ch = Chain(B, P, X.device)
         ch.input_rows(X.contiguous(), dx)
+        from . import chain as _chain
+
         self.x_encoder.append_to(ch).output_pt()
+        imgs = with_tr and _chain.COMPUTE_DTYPE == "bf16"
         if with_tr:
             ch.store_tr()
+        if imgs:
+            ch.store_bf16_images()
         outs = ch.run()
         if with_tr:
             outs[0]._npf_tr = outs[1]  # same activations, [task][feature][point]
+        if imgs:
+            outs[0]._npf_img = (outs[2], outs[3])  # bf16 row / transposed images for the attention chain
         return outs[0]
 
     def _xyenc_pt(self, X_enc_pt, Y, B, P):
@@ -438,8 +445,13 @@ class AttnCNP(NeuralProcessFamily):
         if not isinstance(self.attender, DotAttender):  # learned projections: its own launches
             ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T), self.r_dim)
         elif _chain.COMPUTE_DTYPE == "bf16":
-            # bf16 compute mode: the attention keeps its fp32 launch, the decoder chain behind it is bf16
-            ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T, keys_tr=k_tr, values_tr=v_tr), self.r_dim)
+            k_img, v_img = getattr(Xc_pt, "_npf_img", None), getattr(R, "_npf_img", None)
+            if k_img is not None and v_img is not None and self.attender.fits_fused(C):
+                # bf16 compute mode with bf16 images of keys / values: attention and decoder in one bf16 chain
+                ch.input_pt(Xt_pt, self.x_transf_dim)
+                self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr, keys_img=k_img, values_img=v_img)
+            else:  # the attention keeps an fp32 launch, the decoder chain behind it is bf16
+                ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T, keys_tr=k_tr, values_tr=v_tr), self.r_dim)
         elif self.attender.fits_fused(C):
             ch.input_pt(Xt_pt, self.x_transf_dim)
             self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr)
