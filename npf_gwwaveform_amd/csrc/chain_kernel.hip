@@ -438,9 +438,11 @@ __device__ __forceinline__ void slab_mfma_bf16(const float* slot, int KpF, int S
 // slot per MFMA (~25 cycles per VALU/LDS instruction, ~85 per VMEM instruction;
 // tools/issue_probe.hip).  So the slab DMA, the addend loads and the previous slab's epilogue
 // all ride inside this loop.
-template <int KB16S, int MAXB, class Side>
-__device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w, const f32x4 (&cur)[MAXB], f32x4& acc0,
-                                               f32x4& acc1, Side side) {
+// BF16: KB16S counts 32-feature k-steps (16 floats of a bf16 weight row each), the B operands are the
+// packed `curb`, one v_mfma_f32_16x16x32_bf16 per output block and step.
+template <int KB16S, int MAXB, bool BF16, class Side>
+__device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w, const f32x4 (&cur)[MAXB],
+                                               const bf16x8 (&curb)[MAXB / 2], f32x4& acc0, f32x4& acc1, Side side) {
   constexpr int Kp = 16 * KB16S;
   constexpr int swz = ((Kp >> 2) & 15) ? 7 : 15;
   const int ps = w.p & swz;
@@ -464,10 +466,15 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[(KB16S - 1) & 1][0]), "+v"(fr[(KB16S - 1) & 1][1]));
     }
+    if constexpr (BF16) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[kb & 1][0]), curb[kb], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[kb & 1][1]), curb[kb], acc1, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][0][s], cur[kb][s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][1][s], cur[kb][s], acc1, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][0][s], cur[kb][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[kb & 1][1][s], cur[kb][s], acc1, 0, 0, 0);
+      }
     }
     side(kb);
     __builtin_amdgcn_sched_barrier(0);
@@ -485,7 +492,7 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 //     the bias piece of slab I+1
 //   barrier (slab I consumed by the workgroup, slab I+1 landed).
 // EPI: 0 = out + addend, 1 = relu(out + addend), 2 = addend > 0 ? out : 0.
-template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, class NextLayer>
+template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, class NextLayer>
 __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
                                            f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
                                            const float* addt, int astep, NextLayer next_layer) {
@@ -496,6 +503,11 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
   constexpr int PPB = 4 / E;                                    // epilogue parts per block
   static_assert(2 * NB <= MAXB && KB16S <= MAXB, "layer does not fit the register file");
   f32x4 ad[2] = {};
+  bf16x8 curb[MAXB / 2] = {};
+  if constexpr (BF16) {
+#pragma unroll
+    for (int st = 0; st < KB16S; ++st) curb[st] = pack_bf16(cur[2 * st], cur[2 * st + 1]);
+  }
   auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
     const int j = part >> 1, e0 = (part & 1) * 2;
     f32x4 o = out[2 * I + j];
@@ -520,7 +532,7 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
     out[2 * I + 1] = *(const f32x4*)(bias + 16);
     const char* src = wbase + (size_t)(I + 1) * op.slab_stride * 4;
     const char* bsrc = op.bias != nullptr ? (const char*)(op.bias + (I + 1) * kSlabRows) : (const char*)g_zero128;
-    slab_mfma_side<KB16S, MAXB>(sl, w, cur, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
       if (I > 0 && kb < E) {
 #pragma unroll
         for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
@@ -701,8 +713,8 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       // MFMA loop every VALU instruction of this wave waits for an fp32 MFMA to drain (~32
       // cycles), so what counts outside the MFMA loop is the number of VALU instructions.
       bool fast_shape = false;
-      if constexpr (FKB > 0)
-        fast_shape = KB16 == FKB && N == 32 * FNB && o.i0 == 16 * FKB && g.reserved[0] == 0 &&
+      if constexpr (FKB > 0)  // (bf16 instance: FKB counts 32-feature steps)
+        fast_shape = (BF16 ? o.i0 == 32 * FKB : (KB16 == FKB && o.i0 == 16 * FKB)) && N == 32 * FNB && g.reserved[0] == 0 &&
                      (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast));
       if (fast_shape) {
         if constexpr (FKB > 0) {
@@ -717,9 +729,9 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
               advance();
             }
           };
-          if (mask) fast_layer<2, FKB, FNB, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
-          else if (relu) fast_layer<1, FKB, FNB, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
-          else fast_layer<0, FKB, FNB, MAXB, kPaired>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          if (mask) fast_layer<2, FKB, FNB, MAXB, kPaired, BF16>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else if (relu) fast_layer<1, FKB, FNB, MAXB, kPaired, BF16>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else fast_layer<0, FKB, FNB, MAXB, kPaired, BF16>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
         }
       } else {
       // Generic path: runtime slab loop with *static* register indices: finished blocks enter a register
@@ -1168,7 +1180,7 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
                                     (o.s0 & 3)))
         return NPF_EINVAL;
     }
-    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 0, 0, true>), dim3((unsigned)grid_for(2)), dim3(256), 0,
+    hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 8, 8, true>), dim3((unsigned)grid_for(2)), dim3(256), 0,
                        (hipStream_t)stream, g);
     NPF_CHECK_LAUNCH();
     return NPF_OK;
