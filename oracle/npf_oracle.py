@@ -74,13 +74,25 @@ class OracleConfig:
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
+# Tests may set this to a list: every ReLU then appends the smallest |pre-activation| it saw.  A value
+# within fp32 rounding of zero means the ReLU derivative there is decided by rounding noise, and two
+# correct fp32 implementations can legitimately disagree on the gradient (tests/test_hip_stress.py).
+RELU_MARGINS = None
+
+
+def _relu(v: torch.Tensor) -> torch.Tensor:
+    if RELU_MARGINS is not None and v.numel():
+        RELU_MARGINS.append(float(v.detach().abs().min()))
+    return torch.relu(v)
+
+
 def mlp(params: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
     """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU, no dropout, no
     residual: to_hidden -> relu -> [linears.i -> relu]* -> out (no activation)."""
-    h = torch.relu(F.linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
+    h = _relu(F.linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
     i = 0
     while f"{prefix}.linears.{i}.weight" in params:
-        h = torch.relu(F.linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
+        h = _relu(F.linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
         i += 1
     return F.linear(h, params[f"{prefix}.out.weight"], params[f"{prefix}.out.bias"])
 
@@ -89,7 +101,7 @@ def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tens
     """``MergeFlatInputs.forward`` with ``is_sum_merge=True``
     (npf/architectures/encoders.py:175-183): flat(relu(x1 + resizer(x2)))."""
     x2 = mlp(params, f"{prefix}.resizer", x2)
-    return mlp(params, f"{prefix}.flat_module", torch.relu(x1 + x2))
+    return mlp(params, f"{prefix}.flat_module", _relu(x1 + x2))
 
 
 def scaledot_attend(keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
