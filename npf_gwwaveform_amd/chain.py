@@ -39,7 +39,6 @@ COMPUTE_DTYPE = "fp32"
 _BF16_STEPS = {"input_pt", "input_rows", "linear", "add_pt", "add_taskvec", "tap", "output_pt", "output_rows", "store_tr",
                "store_wb", "store_trb", "softmax"}
 _BF16_ATTN_STEPS = {"attn_scores", "attn_values"}  # eligible when the chain was given bf16 images of keys / values
-_IMG_CACHE: dict = {}
 
 
 def set_compute_dtype(dtype: str) -> None:
@@ -51,17 +50,10 @@ def set_compute_dtype(dtype: str) -> None:
 
 
 def _bf16_image(W: torch.Tensor, transposed: bool) -> torch.Tensor:
-    """Cached ``cast_bf16_weights`` image of a weight tensor, re-cast when the tensor was modified
-    (optimizer step)."""
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
-    hit = _IMG_CACHE.get(key)
-    if hit is not None and hit[0] == W._version:
-        return hit[1]
-    if len(_IMG_CACHE) > 512:
-        _IMG_CACHE.clear()
-    img = cast_bf16_weights(W, transposed=transposed)
-    _IMG_CACHE[key] = (W._version, img)
-    return img
+    """``cast_bf16_weights`` image of a weight tensor.  Not cached: the tensors that reach this point are
+    per-call aliases and temporaries (slices, zero-padded fan-ins) whose addresses get reused, so neither
+    the address nor the version counter identifies their content; a cast is a few microseconds."""
+    return cast_bf16_weights(W, transposed=transposed)
 
 
 def pad32(n: int) -> int:
