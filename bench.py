@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = BASELINE config 2 (headline); bf16 = config 3's compute mode (bf16 MFMA in the MLP stacks, "
                          "fp32 attention / accumulation / weight gradients), 1024 tasks per GPU by default")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the train step from a captured HIP graph (Trainer(use_graph=True); single rank only; "
+                         "skips the per-step host-side input range check) -- not the default measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -270,7 +273,7 @@ def main():
         A.set_compute_dtype("bf16")
     model, crit = build_model(args.model, args.r, args.layers, dev)
     n_params = sum(p.numel() for p in model.parameters())
-    trainer = Trainer(model, crit, lr=1e-3, world=world)
+    trainer = Trainer(model, crit, lr=1e-3, world=world, use_graph=args.graph)
     batches = [synthetic_waveform_batch(B, C, T, 1234 + rank * 10**6 + i, dev) for i in range(4)]
 
     def sync():
@@ -296,6 +299,8 @@ def main():
     roofline = None
     kernels = {}
     n_prof = 3
+    if args.graph:
+        args.no_roofline = True  # (HIP events per launch cannot be recorded inside a graph replay)
     if not args.no_roofline:
         # instrumented pass: HIP events around every kernel launch on the launch stream (rank 0);
         # every rank runs these steps because a step contains the gradient all-reduce
@@ -374,6 +379,7 @@ def main():
                             f"points, {B} tasks per GPU, {args.dtype} train step (fwd+loss+bwd+allreduce+Adam)",
                 "tasks_per_gpu": B, "global_tasks": B * world, "context_points": C, "target_points": T,
                 "r_dim": args.r, "n_params": n_params, "parallelism": f"dp{world}", "final_loss": loss_val,
+                "hip_graph": bool(args.graph),
                 "train_step_tflops_algorithmic": (value * flop_pt * 1e-12) if flop_pt else None,
                 "kernels": kernels,
             },

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--points", type=int, default=128)
     ap.add_argument("--r", type=int, default=128)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (fixed batch shapes)")
     ap.add_argument("--out", default="/tmp/npf_example_ckpt")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -48,9 +49,11 @@ def main():
         model = A.AttnCNP(1, 2, r_dim=args.r, attention="transformer",
                           XYEncoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=2, hidden_size=args.r), is_sum_merge=True),
                           Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=4, hidden_size=args.r), is_sum_merge=True)).to(dev)
-    trainer = Trainer(model, A.CNPFLoss(), lr=1e-3, world=1)
+    trainer = Trainer(model, A.CNPFLoss(), lr=1e-3, world=1, use_graph=args.graph)
     trainer.set_lr_decay(10, max(args.steps // 50, 1))
-    split = A.CntxtTrgtGetter(contexts_getter=A.GetRandomIndcs(a=0.1, b=0.5), targets_getter=A.get_all_indcs)
+    # (a captured graph needs fixed shapes: a fixed number of context points per batch in that mode)
+    n_ctx = dict(a=32, b=32) if args.graph else dict(a=0.1, b=0.5)
+    split = A.CntxtTrgtGetter(contexts_getter=A.GetRandomIndcs(**n_ctx), targets_getter=A.get_all_indcs)
     t0 = time.perf_counter()
     for step in range(args.steps):
         X, Y = functions(args.tasks, args.points, dev, seed=step)

@@ -52,16 +52,51 @@ class Trainer:
     gradient buffers."""
 
     def __init__(self, model: torch.nn.Module, criterion: torch.nn.Module, lr: float = 1e-3, world: Optional[int] = None,
-                 bucket_bytes: int = 2 << 20):
+                 bucket_bytes: int = 2 << 20, use_graph: bool = False):
+        """``use_graph``: capture the whole step (forward, loss, backward, Adam) in a HIP graph after a few
+        eager steps and replay it -- for small models whose step is a string of launch latencies.  Needs
+        fixed batch shapes (a new shape or learning rate re-captures), a single rank, and skips the
+        per-step host-side range check of the inputs (``model.validate_inputs``)."""
         self.model, self.criterion = model, criterion
         self.flat = FlatParameters(model.parameters())
         self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
+        self.use_graph = bool(use_graph) and self.flat.flat.is_cuda and self.reducer.world == 1
         # one fused kernel per step on the flat buffer (the default implementation is ~8 launches)
-        self.opt = torch.optim.Adam([self.flat.flat], lr=lr, fused=self.flat.flat.is_cuda)
+        self.opt = torch.optim.Adam([self.flat.flat], lr=lr, fused=self.flat.flat.is_cuda, capturable=self.use_graph)
         self.model.train()
         self.criterion.train()
+        self._graph = None
+        self._eager_steps = 0
 
     def step(self, batch: dict) -> torch.Tensor:
+        if self.use_graph:
+            return self._graph_step(batch)
+        return self._eager_step(batch)
+
+    def _graph_step(self, batch: dict) -> torch.Tensor:
+        sig = (tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())), float(self.opt.param_groups[0]["lr"]))
+        if self._graph is not None and sig != self._graph_sig:
+            self._graph = None  # new shapes / learning rate: capture again
+        if self._graph is None:
+            if self._eager_steps < 3:  # allocator warm-up and lazy initialisations happen eagerly
+                self._eager_steps += 1
+                return self._eager_step(batch)
+            was, self.model.validate_inputs = self.model.validate_inputs, False
+            try:
+                self._static = {k: v.clone() for k, v in batch.items()}
+                torch.cuda.synchronize()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._static_loss = self._eager_step(self._static)
+            finally:
+                self.model.validate_inputs = was
+            self._graph_sig = sig  # (a capture records, it does not execute: this batch runs in the replay below)
+        for k, v in batch.items():
+            self._static[k].copy_(v)
+        self._graph.replay()
+        return self._static_loss.clone()
+
+    def _eager_step(self, batch: dict) -> torch.Tensor:
         for p in self.flat.params:
             p.grad = None
         self.reducer.reset()
