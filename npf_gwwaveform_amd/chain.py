@@ -78,6 +78,17 @@ def _pad_vec(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pt16_shape(n_tasks: int, pts: int, F: int):
+    """PT16: the bf16 tile layout of the bf16 compute mode -- [n_tasks, tiles, F/8 rows, 32 points, 8 features], the 8
+    features of row 4 s + g being {32 s + 4 g + i} and {32 s + 16 + 4 g + i}, i < 4 (a lane's values of two adjacent
+    16-feature blocks: one 16-byte access per lane and 32-feature group)."""
+    return (n_tasks, tiles_of(pts), pad32(F) // 8, 32, 8)
+
+
+def pt16_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
+    return torch.empty(pt16_shape(n_tasks, pts, F), dtype=torch.bfloat16, device=device)
+
+
 def pt_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
     return torch.empty(pt_shape(n_tasks, pts, F), dtype=torch.float32, device=device)
 
@@ -279,13 +290,19 @@ def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
         chunk = jobs[i0:i0 + L.NPF_MAX_WGRAD_JOBS]
         arr = (L.NpfWgradJob * len(chunk))()
         for j, jb in enumerate(chunk):
-            arr[j].dZ, arr[j].A, arr[j].dW = L.ptr(jb["dZ"]), L.ptr(jb["A"]), L.ptr(jb["dW"])
+            z16, a16 = jb["dZ"].dtype == torch.bfloat16, jb["A"].dtype == torch.bfloat16  # PT16 operands (bf16 mode)
+            if (z16 or a16) and COMPUTE_DTYPE != "bf16":
+                raise RuntimeError("PT16 operands exist in the bf16 compute mode only")
+            arr[j].dZ = jb["dZ"].data_ptr() if z16 else L.ptr(jb["dZ"])
+            arr[j].A = jb["A"].data_ptr() if a16 else L.ptr(jb["A"])
+            arr[j].dW = L.ptr(jb["dW"])
             arr[j].db = L.ptr(jb.get("db"))
             arr[j].ldw = jb.get("ldw") or jb["K"]
             arr[j].N, arr[j].K = jb["N"], jb["K"]
             arr[j].per_task = int(jb.get("per_task", False))
             # bit 1: bf16 products (bf16 compute mode: every weight / key / value gradient of the step)
-            arr[j].accumulate = int(jb.get("accumulate", False)) | (2 if COMPUTE_DTYPE == "bf16" else 0)
+            arr[j].accumulate = (int(jb.get("accumulate", False)) | (2 if COMPUTE_DTYPE == "bf16" else 0)
+                                 | (4 if z16 else 0) | (8 if a16 else 0))
         nbytes = lib.npf_wgrad_partials_bytes(arr, len(chunk), n_tasks, tiles_of(pts))
         if nbytes < 0:
             raise RuntimeError("npf_wgrad_partials_bytes: invalid wgrad jobs")

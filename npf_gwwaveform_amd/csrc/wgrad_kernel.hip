@@ -53,6 +53,59 @@ __device__ __forceinline__ bf16x4 pack4_bf16(float a, float b, float c, float d)
   return r;
 }
 
+// The four bf16x4 operands (features m = 0..3 of this lane's row, 4 consecutive points each) of one 16-point
+// step, from an fp32 tile image (lane row = quad row 16 blk + i: 4 x ds_read_b128, rounded here) or from a
+// PT16 tile image (lane row = half h = i >> 3 of the 8-feature row 8 blk + (i & 7): 4 x ds_read_b64, the
+// 16-bit values regrouped with v_perm).  `dsum`: accumulates the sum over the points (bias gradient).
+__device__ __forceinline__ void operand16(const float* img, bool fmt16, int blk, int i, int g, int t2, bf16x4 (&op)[4],
+                                          f32x4* dsum) {
+  if (!fmt16) {
+    f32x4 q[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int c = 16 * t2 + 4 * g + jj;
+      q[jj] = *(const f32x4*)(img + (16 * blk + i) * 128 + ((c ^ i) << 2));
+    }
+    if (dsum) *dsum += (q[0] + q[1]) + (q[2] + q[3]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) op[m] = pack4_bf16(q[0][m], q[1][m], q[2][m], q[3][m]);
+  } else {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int o = 8 * blk + (i & 7), h = i >> 3;
+    u32x2 q[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int c = 16 * t2 + 4 * g + jj;
+      q[jj] = *(const u32x2*)(img + o * 128 + ((c ^ (o & 15)) << 2) + 2 * h);
+    }
+    if (dsum) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        (*dsum)[0] += __builtin_bit_cast(float, q[jj][0] << 16);
+        (*dsum)[1] += __builtin_bit_cast(float, q[jj][0] & 0xffff0000u);
+        (*dsum)[2] += __builtin_bit_cast(float, q[jj][1] << 16);
+        (*dsum)[3] += __builtin_bit_cast(float, q[jj][1] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int w = m >> 1;
+      const unsigned sel = (m & 1) ? 0x07060302u : 0x05040100u;  // the high / low 16 bits of the two sources
+      u32x2 r;
+      r[0] = __builtin_amdgcn_perm(q[1][w], q[0][w], sel);
+      r[1] = __builtin_amdgcn_perm(q[3][w], q[2][w], sel);
+      op[m] = __builtin_bit_cast(bf16x4, r);
+    }
+  }
+}
+
+// Feature index of (64-feature block, operand lane row i, element m) for the two tile formats.
+__device__ __forceinline__ int wg_feature(bool fmt16, int blk, int i, int m) {
+  if (!fmt16) return 4 * (16 * blk + i) + m;
+  const int o = 8 * blk + (i & 7);
+  return 32 * (o >> 2) + 16 * (i >> 3) + 4 * (o & 3) + m;
+}
+
 // BF16: the same contraction with the operands rounded to bf16 at the MFMA input
 // (v_mfma_f32_16x16x16_bf16, fp32 accumulation): the k-slots of a lane group are 4 consecutive points, so
 // a lane reads its quad row at 4 points (4 x ds_read_b128 per operand) and forms the 4 + 4 operands of
@@ -108,12 +161,16 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   const char* dz_base = (const char*)job.dZ;
   const char* a_base = (const char*)job.A;
   asm volatile("" : "+s"(dz_base), "+s"(a_base));
+  // PT16 operands (bf16 variant only, NPF_WGRAD_DZ16 / NPF_WGRAD_A16): a tile is [F/8 rows of 8 features][32
+  // points] 16-byte chunks = half the bytes and half the rows of the fp32 tile; same 512-byte rows, same swizzle.
+  const bool z16 = BF16 && (job.accumulate & NPF_WGRAD_DZ16) != 0, a16 = BF16 && (job.accumulate & NPF_WGRAD_A16) != 0;
+  const int zsh = z16 ? 4 : 3, ash = a16 ? 4 : 3;  // pieces per tile = F >> sh, tile bytes = F << (10 - sh)
   auto tile_dma = [&](long t, float* buf) {
-    const char* zsrc = dz_base + (size_t)t * Np * 128;
-    const char* asrc = a_base + (size_t)t * Kp * 128;
-    for (int q = wave; q < (Np >> 3); q += kWgWaves)
+    const char* zsrc = dz_base + (((size_t)t * Np) << (10 - zsh));
+    const char* asrc = a_base + (((size_t)t * Kp) << (10 - ash));
+    for (int q = wave; q < (Np >> zsh); q += kWgWaves)
       wg_dma16((const float*)(zsrc + (size_t)q * 1024 + (size_t)dma_lane), buf + q * 256);
-    for (int q = wave; q < (Kp >> 3); q += kWgWaves)
+    for (int q = wave; q < (Kp >> ash); q += kWgWaves)
       wg_dma16((const float*)(asrc + (size_t)q * 1024 + (size_t)dma_lane), buf + kOp + q * 256);
   };
 
@@ -140,23 +197,14 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
     const unsigned boff = cur * 2 * kOp * 4;
     if constexpr (BF16) {
       if (act) {
+        const float* zimg = lds + cur * 2 * kOp;
+        const float* aimg = zimg + kOp;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-          // points 16 t2 + 4 g + j, j < 4: chunk c of quad row r lives at chunk position c ^ (r & 15)
-          f32x4 qa[4], qb[4];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int c = 16 * t2 + 4 * g + jj;
-            qa[jj] = *(const f32x4*)(lds + cur * 2 * kOp + (16 * rg + i) * 128 + ((c ^ i) << 2));
-            qb[jj] = *(const f32x4*)(lds + cur * 2 * kOp + kOp + (16 * cg + i) * 128 + ((c ^ i) << 2));
-          }
-          if (cg == 0) dbacc += (qa[0] + qa[1]) + (qa[2] + qa[3]);
+          // points 16 t2 + 4 g + j, j < 4: chunk c of row r lives at chunk position c ^ (r & 15)
           bf16x4 am[4], bn[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            am[m] = pack4_bf16(qa[0][m], qa[1][m], qa[2][m], qa[3][m]);
-            bn[m] = pack4_bf16(qb[0][m], qb[1][m], qb[2][m], qb[3][m]);
-          }
+          operand16(zimg, z16, rg, i, g, t2, am, cg == 0 ? &dbacc : nullptr);
+          operand16(aimg, a16, cg, i, g, t2, bn, nullptr);
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -195,7 +243,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   // ---- write out --------------------------------------------------------------------
   // acc[m][n][e] on lane (i, g) = D[row 4*(16rg + 4g + e) + m][col 4*(16cg + i) + n]
   if (act) {
-    const int col = 4 * (16 * cg + i);
+    const int col = wg_feature(a16, cg, i, 0);  // (the 4 values n = 0..3 are the next 4 features in both formats)
     if (job.per_task) {
       // PT32 tensor, points = row index (n of dW), features = column index (k)
       float* out = job.dW + (size_t)split * ((Np >> 5) * Kp * 32);
@@ -203,7 +251,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int row = 4 * (16 * rg + 4 * g + e) + m;
+          const int row = wg_feature(z16, rg, 4 * g + e, m);
           if (row < Np && col < Kp) {
             f32x4 v;
 #pragma unroll
@@ -219,7 +267,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int row = 4 * (16 * rg + 4 * g + e) + m;
+          const int row = wg_feature(z16, rg, 4 * g + e, m);
           if (row < Np && col < Kp) {
             f32x4 v;
 #pragma unroll
@@ -234,7 +282,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
           dbacc[m] += __shfl_xor(dbacc[m], 16);
           dbacc[m] += __shfl_xor(dbacc[m], 32);
         }
-        if (g == 0 && 4 * (16 * rg + i) < Np) *(f32x4*)(part + (size_t)Np * Kp + 4 * (16 * rg + i)) = dbacc;
+        if (g == 0 && wg_feature(z16, rg, i, 0) < Np) *(f32x4*)(part + (size_t)Np * Kp + wg_feature(z16, rg, i, 0)) = dbacc;
       }
     }
   }

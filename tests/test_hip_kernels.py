@@ -328,3 +328,36 @@ def test_bf16_wgrad_matches_bf16_emulation():
             CH.COMPUTE_DTYPE = "fp32"
         assert_close(dW, ref, tol=1e-4, what=f"bf16 wgrad {N}x{K}")
         assert_close(db, dz.double().sum((0, 1)), tol=1e-5, what="bf16 wgrad db")
+
+
+def _pack_pt16_reference(x):
+    """Row-major [B, P, F] -> PT16 (bf16 tiles) with plain torch ops (the layout of chain.pt16_shape)."""
+    B, P, F = x.shape
+    Fp, tiles = (F + 31) // 32 * 32, (P + 31) // 32
+    xp = torch.zeros(B, tiles * 32, Fp)
+    xp[:, :P, :F] = x
+    # feature f = 32 s + 16 h + 4 g + i  ->  [B, tiles, s, g, p, (h, i)]
+    v = xp.view(B, tiles, 32, Fp // 32, 2, 4, 4).permute(0, 1, 3, 5, 2, 4, 6).contiguous()
+    return v.view(B, tiles, Fp // 8, 32, 8).to(torch.bfloat16)
+
+
+def test_bf16_wgrad_with_pt16_operands():
+    """wgrad kernel, bf16 variant, with one or both operands given as PT16 tensors (bf16 tiles): same result
+    as with the fp32 tiles of the same bf16-rounded values."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(43)
+    for n_tasks, pts, N, K in ((3, 70, 256, 256), (2, 45, 100, 36), (1, 200, 32, 256), (2, 33, 64, 160)):
+        dz, a = _bf16_round(torch.randn(n_tasks, pts, N, generator=g)), _bf16_round(torch.randn(n_tasks, pts, K, generator=g))
+        ref = torch.einsum("bpn,bpk->nk", dz.double(), a.double())
+        for z16, a16 in ((True, True), (True, False), (False, True)):
+            dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+            opz = _pack_pt16_reference(dz).to(DEV) if z16 else FN.pack_pt(dz.to(DEV))
+            opa = _pack_pt16_reference(a).to(DEV) if a16 else FN.pack_pt(a.to(DEV))
+            assert tuple(opz.shape) == (CH.pt16_shape(n_tasks, pts, N) if z16 else CH.pt_shape(n_tasks, pts, N))
+            CH.COMPUTE_DTYPE = "bf16"
+            try:
+                CH.run_wgrad([dict(dZ=opz, A=opa, N=N, K=K, dW=dW, db=db)], n_tasks, pts, DEV)
+            finally:
+                CH.COMPUTE_DTYPE = "fp32"
+            assert_close(dW, ref, tol=1e-5, what=f"pt16 wgrad {N}x{K} z16={z16} a16={a16}")
+            assert_close(db, dz.double().sum((0, 1)), tol=1e-5, what="pt16 wgrad db")
