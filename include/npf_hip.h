@@ -102,6 +102,9 @@ enum npf_wmode {
 #define NPF_F_RELU 1u
 #define NPF_F_ADD_PT 2u /* add PT32 tensor p2 (same F as the output) before the activation     */
 #define NPF_F_MASK_PT 4u /* out = (PT32 tensor p2 > 0) ? out : 0 (fused relu backward); not with ADD_PT */
+#define NPF_F_P16 16u     /* bf16 mode only: the op's PT tensor (p0 of LOAD_PT / STORE_PT / ADD_PT / MASK_POS /
+                            ROWDOT_PT / SOFTMAX_BWD, p2 of a LINEAR's addend or mask) is a PT16 tensor: bf16 tiles
+                            [F/8 rows][32 points][8 features], row 4s+g = features {32s+4g+i}, {32s+16+4g+i}     */
 #define NPF_F_ADD_RM 8u  /* like ADD_PT with a row-major addend p2 [task][pt][i1] (i1 % 32 == 0): module-
                             boundary tensors enter without a layout pass (inference paths)            */
 

@@ -23,7 +23,7 @@ OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFT
     OP_ADD_TASKVEC, OP_ROWDOT_PT, OP_SOFTMAX_BWD, OP_RELU, OP_SCALE, OP_STORE_TR, OP_LAYERNORM, OP_LAYERNORM_BWD, OP_LOAD_RM, OP_STORE_WB, OP_STORE_TRB = range(20)
 # weight modes (enum npf_wmode)
 W_ROWMAJOR, W_PT_ROWS, W_PT_COLS = range(3)
-F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM = 1, 2, 4, 8
+F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16 = 1, 2, 4, 8, 16
 
 
 class NpfOp(C.Structure):

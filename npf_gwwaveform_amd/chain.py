@@ -119,18 +119,31 @@ class Program:
         self.keep.append(t)
         return L.ptr(t)
 
+    def _pt(self, t: torch.Tensor):
+        """(pointer, flags) of a PT operand: fp32 PT32, or a bf16 PT16 tensor (bf16 compute mode)."""
+        if t.dtype == torch.bfloat16:
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("PT16 tensors must be contiguous device tensors")
+            self.keep.append(t)
+            self.bf16 = True
+            return t.data_ptr(), L.F_P16
+        return self._p(t), 0
+
     def load_pt(self, t, F, modulus=0):
-        self._op(op=L.OP_LOAD_PT, i0=pad32(F), i4=modulus, p0=self._p(t))
+        p, fl = self._pt(t)
+        self._op(op=L.OP_LOAD_PT, i0=pad32(F), i4=modulus, p0=p, flags=fl)
 
     def load_rm(self, t, F, modulus=0):
         """cur <- row-major [n_tasks (or modulus), pts, F] tensor, F a multiple of 32."""
         self._op(op=L.OP_LOAD_RM, i0=F, i4=modulus, p0=self._p(t))
 
     def store_pt(self, t, F):
-        self._op(op=L.OP_STORE_PT, i0=pad32(F), p0=self._p(t))
+        p, fl = self._pt(t)
+        self._op(op=L.OP_STORE_PT, i0=pad32(F), p0=p, flags=fl)
 
     def add_pt(self, t, F, relu=False, modulus=0):
-        self._op(op=L.OP_ADD_PT, i0=pad32(F), i1=int(relu), i4=modulus, p0=self._p(t))
+        p, fl = self._pt(t)
+        self._op(op=L.OP_ADD_PT, i0=pad32(F), i1=int(relu), i4=modulus, p0=p, flags=fl)
 
     def mask_pos(self, t, F):
         last = self.ops[-1] if self.ops else None
@@ -138,17 +151,21 @@ class Program:
                 and pad32(last.i1) == pad32(F)):
             # fuse the relu-backward mask into the producing layer's epilogue: the mask tile is
             # then prefetched under that layer's MFMAs instead of being waited for afterwards
-            last.flags |= L.F_MASK_PT
-            last.p2 = self._p(t)
+            p, fl = self._pt(t)
+            last.flags |= L.F_MASK_PT | fl
+            last.p2 = p
             last.i4 = 0
             return
-        self._op(op=L.OP_MASK_POS, i0=pad32(F), p0=self._p(t))
+        p, fl = self._pt(t)
+        self._op(op=L.OP_MASK_POS, i0=pad32(F), p0=p, flags=fl)
 
     def rowdot_pt(self, t, F):
-        self._op(op=L.OP_ROWDOT_PT, i0=pad32(F), p0=self._p(t))
+        p, fl = self._pt(t)
+        self._op(op=L.OP_ROWDOT_PT, i0=pad32(F), p0=p, flags=fl)
 
     def softmax_bwd(self, t, F, scale):
-        self._op(op=L.OP_SOFTMAX_BWD, i0=pad32(F), f0=scale, p0=self._p(t))
+        p, fl = self._pt(t)
+        self._op(op=L.OP_SOFTMAX_BWD, i0=pad32(F), f0=scale, p0=p, flags=fl)
 
     def store_tr(self, t, F, ld):
         self._op(op=L.OP_STORE_TR, i0=F, i1=ld, p0=self._p(t))
@@ -226,7 +243,7 @@ class Program:
         for o in self.ops:
             if o.op in (L.OP_LOAD_PT, L.OP_STORE_PT, L.OP_ADD_PT, L.OP_MASK_POS, L.OP_ROWDOT_PT, L.OP_SOFTMAX_BWD,
                         L.OP_LOAD_RM):
-                per_pt += 4 * o.i0
+                per_pt += (2 if o.flags & L.F_P16 else 4) * o.i0
             elif o.op in (L.OP_LOAD_ROWS, L.OP_STORE_ROWS, L.OP_STORE_TR):
                 per_pt += 4 * o.i0
             elif o.op in (L.OP_STORE_WB, L.OP_STORE_TRB):
@@ -237,7 +254,7 @@ class Program:
                 per_pt += 4 * pad32(o.i0) * (2 if o.p2 else 1)
             elif o.op == L.OP_LINEAR:
                 if o.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_ADD_RM):
-                    per_pt += 4 * pad32(o.i1)
+                    per_pt += (2 if o.flags & L.F_P16 else 4) * pad32(o.i1)
                 per_task = o.i2 != L.W_ROWMAJOR or o.s0 != 0
                 fixed += 4 * o.i0 * o.i1 * (self.n_tasks if per_task else 1)
         return per_pt * pts + fixed
@@ -277,7 +294,7 @@ def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
         _run_wgrad(jobs, n_tasks, pts, device)
         ev1.record()
         padded = n_tasks * tiles_of(pts) * 32
-        nbytes = sum(4 * (pad32(j["N"]) + pad32(j["K"])) * padded
+        nbytes = sum((j["dZ"].element_size() * pad32(j["N"]) + j["A"].element_size() * pad32(j["K"])) * padded
                      + 4 * j["N"] * j["K"] * (n_tasks if j.get("per_task") else 1) for j in jobs)
         PROFILE.append(("wgrad_kernel", sum(2 * j["N"] * j["K"] for j in jobs) * n_tasks * pts, ev0, ev1, nbytes))
     else:
@@ -518,8 +535,17 @@ class _ChainFn(torch.autograd.Function):
         upstream = False  # does cur depend on something that needs a gradient
         upstream_before = []
 
-        def ensure_saved(F):
-            nonlocal backed
+        backed16 = None  # bf16 mode: PT16 copy of cur kept for the backward pass only (mask / wgrad operand)
+
+        def ensure_saved(F, internal=False):
+            """A tensor holding cur: an fp32 PT32 tensor (required for outputs and for operands of fp32-only
+            consumers), or -- bf16 mode, ``internal`` -- a PT16 tensor at half the HBM traffic."""
+            nonlocal backed, backed16
+            if internal and bf16 and backed is None:
+                if backed16 is None:
+                    backed16 = pt16_empty(chain.n_tasks, chain.pts, F, dev)
+                    prog.store_pt(backed16, F)
+                return backed16
             if backed is None:
                 backed = pt_empty(chain.n_tasks, chain.pts, F, dev)
                 prog.store_pt(backed, F)
@@ -531,21 +557,22 @@ class _ChainFn(torch.autograd.Function):
             if k == "input_pt":
                 prog.load_pt(T[st.t["x"]], a["F"], a["mod"])
                 backed = T[st.t["x"]] if a["mod"] == 0 else None
+                backed16 = None
                 upstream = needs_grad[st.t["x"]]
             elif k == "input_rm":
                 if train and needs_grad[st.t["x"]]:
                     raise NotImplementedError("row-major chain inputs carry no gradient (inference path)")
                 prog.load_rm(T[st.t["x"]], a["F"], a["mod"])
-                backed = None
+                backed = backed16 = None
                 upstream = False
             elif k == "input_rows":
                 prog.load_rows(T[st.t["x"]], a["kd"], a["mod"])
-                backed = None
+                backed = backed16 = None
                 upstream = False
             elif k == "linear":
                 W, b, add = st.t["W"], st.t["b"], st.t["add"]
                 if train and (needs_grad[W] or (b >= 0 and needs_grad[b])):
-                    saved[(i, "in")] = ensure_saved(a["K"])
+                    saved[(i, "in")] = ensure_saved(a["K"], internal=True)
                 if a.get("add_rm") and train and (upstream or needs_grad[W] or needs_grad[add]):
                     raise NotImplementedError("row-major addends carry no gradient (inference path)")
                 if bf16:
@@ -556,48 +583,48 @@ class _ChainFn(torch.autograd.Function):
                     prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
                                 addend=T[add] if add >= 0 else None, addend_modulus=a["mod"], ldw=T[W].stride(0),
                                 b_task_stride=(T[b].stride(0) if a["bpt"] else 0), addend_rm=bool(a.get("add_rm")))
-                backed = None
+                backed = backed16 = None
                 upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if train and a["relu"] and upstream:
-                    saved[(i, "out")] = ensure_saved(a["N"])
+                    saved[(i, "out")] = ensure_saved(a["N"], internal=True)
             elif k == "add_pt":
                 prog.add_pt(T[st.t["x"]], a["F"], a["relu"], a["mod"])
-                backed = None
+                backed = backed16 = None
                 upstream = upstream or needs_grad[st.t["x"]]
                 if train and a["relu"] and upstream:
-                    saved[(i, "out")] = ensure_saved(a["F"])
+                    saved[(i, "out")] = ensure_saved(a["F"], internal=True)
             elif k == "add_taskvec":
                 prog.add_taskvec(T[st.t["v"]], a["F"], a["relu"], a["mod"])
-                backed = None
+                backed = backed16 = None
                 upstream = upstream or needs_grad[st.t["v"]]
                 if train and a["relu"] and upstream:
-                    saved[(i, "out")] = ensure_saved(a["F"])
+                    saved[(i, "out")] = ensure_saved(a["F"], internal=True)
             elif k == "layernorm":
                 gi, bi = st.t["g"], st.t["b"]
                 upstream = upstream or needs_grad[gi] or needs_grad[bi]
                 if train and upstream:
                     saved[(i, "in")] = ensure_saved(a["F"])
                 prog.layernorm(_pad_vec(T[gi]), _pad_vec(T[bi]), a["F"], a["eps"])
-                backed = None
+                backed = backed16 = None
             elif k == "attn_scores":
                 kk = st.t["k"]
                 if train and needs_grad[kk]:
-                    saved[(i, "in")] = ensure_saved(a["r"])
+                    saved[(i, "in")] = ensure_saved(a["r"], internal=True)
                 if bf16:
                     prog.linear_bf16(a["img"][0], a["r"], a["C"], per_task=True)
                 else:
                     prog.linear(T[kk], a["r"], a["C"], mode=L.W_PT_ROWS, w_tiles=ctx_tiles(kk))
-                backed = None
+                backed = backed16 = None
                 upstream = upstream or needs_grad[kk]
             elif k == "softmax":
                 prog.softmax(a["n"], a["scale"])
-                backed = None
+                backed = backed16 = None
                 if train and upstream:
-                    saved[(i, "out")] = ensure_saved(a["n"])
+                    saved[(i, "out")] = ensure_saved(a["n"], internal=True)
             elif k == "attn_values":
                 vv = st.t["v"]
                 if train and needs_grad[vv]:
-                    saved[(i, "in")] = ensure_saved(a["C"])
+                    saved[(i, "in")] = ensure_saved(a["C"], internal=True)
                 if bf16:
                     prog.linear_bf16(a["img"][1], a["C"], a["r"], per_task=True)
                 elif a["tr"] is not None:
@@ -605,7 +632,7 @@ class _ChainFn(torch.autograd.Function):
                     prog.linear(a["tr"], a["C"], a["r"], mode=L.W_ROWMAJOR, ldw=ld, w_task_stride=a["r"] * ld)
                 else:
                     prog.linear(T[vv], a["C"], a["r"], mode=L.W_PT_COLS, w_tiles=ctx_tiles(vv))
-                backed = None
+                backed = backed16 = None
                 upstream = upstream or needs_grad[vv]
             elif k == "store_tr":
                 o = torch.empty((chain.n_tasks, a["F"], 32 * tiles_of(chain.pts)), dtype=torch.float32, device=dev)
@@ -624,7 +651,7 @@ class _ChainFn(torch.autograd.Function):
             elif k in ("tap", "output_pt"):
                 # an output must own its storage: never alias an input tensor
                 if backed is not None and any(backed is t for t in T):
-                    backed = None
+                    backed = backed16 = None
                 outputs.append(ensure_saved(a["F"]))
             elif k == "output_rows":
                 o = torch.empty((chain.n_tasks, chain.pts, a["nd"]), dtype=torch.float32, device=dev)
@@ -654,7 +681,11 @@ class _ChainFn(torch.autograd.Function):
         gouts = list(gouts)
         started = False  # has cur been initialised with a gradient yet
 
-        def new_pt(F):
+        def new_pt(F, internal=False):
+            """Gradient buffer: fp32 PT32 when it is returned to autograd or reduced by an fp32 kernel; in the bf16
+            mode a PT16 tensor when it only feeds the wgrad kernel (``internal``)."""
+            if internal and ctx.bf16:
+                return pt16_empty(chain.n_tasks, chain.pts, F, dev)
             return pt_empty(chain.n_tasks, chain.pts, F, dev)
 
         def acc_grad(idx, g):
@@ -695,7 +726,7 @@ class _ChainFn(torch.autograd.Function):
                     prog.mask_pos(saved[(i, "out")], a["N"])
                 need_dz = needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if need_dz:
-                    dz = new_pt(a["N"])
+                    dz = new_pt(a["N"], internal=not ((add >= 0 and needs_grad[add]) or (b >= 0 and a["bpt"] and needs_grad[b])))
                     prog.store_pt(dz, a["N"])
                     if needs_grad[W] or (b >= 0 and needs_grad[b]):
                         dW = torch.empty((a["N"], a["K"]), dtype=torch.float32, device=dev)
@@ -742,7 +773,7 @@ class _ChainFn(torch.autograd.Function):
             elif k == "attn_values":
                 vv = st.t["v"]
                 if needs_grad[vv]:
-                    dO = new_pt(a["r"])
+                    dO = new_pt(a["r"], internal=True)
                     prog.store_pt(dO, a["r"])
                     dV = torch.empty_like(T[vv])
                     jobs.append(dict(dZ=saved[(i, "in")], A=dO, N=a["C"], K=a["r"], dW=dV, per_task=True))
@@ -758,7 +789,7 @@ class _ChainFn(torch.autograd.Function):
             elif k == "attn_scores":
                 kk = st.t["k"]
                 if needs_grad[kk]:
-                    dS = new_pt(a["C"])
+                    dS = new_pt(a["C"], internal=True)
                     prog.store_pt(dS, a["C"])
                     dK = torch.empty_like(T[kk])
                     jobs.append(dict(dZ=dS, A=saved[(i, "in")], N=a["C"], K=a["r"], dW=dK, per_task=True))

@@ -407,6 +407,24 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4& lo, const f32x4& hi) {
   return r;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// the two f32x4 (blocks 2s, 2s+1 of the lane) held by one 16-byte PT16 chunk
+__device__ __forceinline__ f32x4 pt16_lo(const u32x4& r) {
+  return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 pt16_hi(const u32x4& r) {
+  return f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+}
+// Pointer (bf16 units) to this lane's chunk of feature group 0 of its tile in a PT16 tensor with F features;
+// group s is at + 1024 s.
+__device__ __forceinline__ const unsigned short* pt16_lane(const void* base, const npf_program_t& g, const Wave& w, int F,
+                                                           int modulus) {
+  const size_t tile = (size_t)eff_task(w, modulus) * g.tiles_per_task + w.tile_in_task;
+  return (const unsigned short*)base + (tile * (size_t)(F >> 3) * 32 + (16 * w.half + w.p)) * 8 + w.g * 256;
+}
+
 template <int NBLK, int MAXB>
 __device__ __forceinline__ void slab_mfma_bf16(const float* slot, int KpF, int S, const Wave& w,
                                                const bf16x8 (&curb)[MAXB / 2], f32x4 (&acc)[kBlk]) {
@@ -492,7 +510,7 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 //     the bias piece of slab I+1
 //   barrier (slab I consumed by the workgroup, slab I+1 landed).
 // EPI: 0 = out + addend, 1 = relu(out + addend), 2 = addend > 0 ? out : 0.
-template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, class NextLayer>
+template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class NextLayer>
 __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
                                            f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
                                            const float* addt, int astep, NextLayer next_layer) {
@@ -513,9 +531,16 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
     f32x4 o = out[2 * I + j];
 #pragma unroll
     for (int e = e0; e < e0 + 2; ++e) {
-      if (EPI == 2) o[e] = ad[j][e] > 0.f ? o[e] : 0.f;
-      else if (EPI == 1) o[e] = fmaxf(o[e] + ad[j][e], 0.f);
-      else o[e] = o[e] + ad[j][e];
+      float a;
+      if constexpr (P16) {  // element e of block j = 16-bit half (e & 1) of raw word 2 j + (e >> 1)
+        const unsigned wd = __builtin_bit_cast(u32x4, ad[0])[2 * j + (e >> 1)];
+        a = __builtin_bit_cast(float, (e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+      } else {
+        a = ad[j][e];
+      }
+      if (EPI == 2) o[e] = a > 0.f ? o[e] : 0.f;
+      else if (EPI == 1) o[e] = fmaxf(o[e] + a, 0.f);
+      else o[e] = o[e] + a;
     }
     out[2 * I + j] = o;
   };
@@ -538,8 +563,12 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
         for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
       }
       if (kb == E) {  // (HBM latency: these must be long gone before the barrier drains vmcnt)
-        ad[0] = *(const f32x4*)(addt + (8 * I + w.g) * astep);
-        ad[1] = *(const f32x4*)(addt + (8 * I + 4 + w.g) * astep);
+        if constexpr (P16) {  // PT16 mask / addend: one 16-byte chunk per slab, kept raw and unpacked at use
+          ad[0] = *(const f32x4*)(addt + 512 * I);
+        } else {
+          ad[0] = *(const f32x4*)(addt + (8 * I + w.g) * astep);
+          ad[1] = *(const f32x4*)(addt + (8 * I + 4 + w.g) * astep);
+        }
       }
       if (I < NB - 1 && (!PAIRED || issuer)) {
 #pragma unroll
@@ -700,11 +729,16 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       const int NB = (N + kSlabRows - 1) / kSlabRows;
       const bool relu = (o.flags & NPF_F_RELU) != 0;
       const bool mask = (o.flags & NPF_F_MASK_PT) != 0;  // out = (tile > 0) ? acc : 0  (relu backward)
-      const bool add = ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid;
+      const bool add = ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid & !(BF16 && (o.flags & NPF_F_P16));
+      [[maybe_unused]] const bool add16 = BF16 && ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid & ((o.flags & NPF_F_P16) != 0);
       const bool add_rm = ((o.flags & NPF_F_ADD_RM) != 0) & w.valid;  // row-major addend: feature quad stride 4 floats
       const float* addt = add ? pt_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4)
                               : (add_rm ? rm_lane(o.p2, g, w, pt, N, o.i4) : Z);
       const int astep = add ? 128 : (add_rm ? 4 : 0);  // (no addend: every load reads the zero buffer)
+      // bf16 instance: the addend / mask may be a PT16 tensor: one chunk per slab at addt16 + 1024 nb (bf16 units)
+      [[maybe_unused]] const bool p16 = add16;
+      [[maybe_unused]] const unsigned short* addt16 =
+          p16 ? pt16_lane(o.p2, g, w, ((N + 31) >> 5) * 32, o.i4) : (const unsigned short*)Z;
       NPF_STAMP(5)  // everything between LINEAR slab loops (other ops, layer setup)
       // Fast path for the 256 -> 256 layers (all the heavy ones at r = 256, attention included):
       // the 8 slab steps are unrolled, so the epilogue writes the slab's own two output blocks
@@ -715,7 +749,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       bool fast_shape = false;
       if constexpr (FKB > 0)  // (bf16 instance: FKB counts 32-feature steps)
         fast_shape = (BF16 ? o.i0 == 32 * FKB : (KB16 == FKB && o.i0 == 16 * FKB)) && N == 32 * FNB && g.reserved[0] == 0 &&
-                     (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast));
+                     (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast)) && !(p16 && !mask);
       if (fast_shape) {
         if constexpr (FKB > 0) {
           // this layer's slabs 1.. stream inside the pipeline; then the cursor jumps to the next
@@ -729,9 +763,12 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
               advance();
             }
           };
-          if (mask) fast_layer<2, FKB, FNB, MAXB, kPaired, BF16>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
-          else if (relu) fast_layer<1, FKB, FNB, MAXB, kPaired, BF16>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
-          else fast_layer<0, FKB, FNB, MAXB, kPaired, BF16>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          if (mask && p16) {
+            if constexpr (BF16)
+              fast_layer<2, FKB, FNB, MAXB, kPaired, BF16, true>(w, smem, slot, cur, out, pfs, issuer, grp_b, (const float*)addt16, 0, next_layer);
+          } else if (mask) fast_layer<2, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else if (relu) fast_layer<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
+          else fast_layer<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
         }
       } else {
       // Generic path: runtime slab loop with *static* register indices: finished blocks enter a register
@@ -754,6 +791,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         f32x4 ad[kBlk];
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) ad[j] = *(const f32x4*)(addt + (4 * kBlk * nb + 4 * j + w.g) * astep);
+        if constexpr (BF16) {
+          if (p16) {  // (the fp32 loads above read the zero buffer in this case: astep applies to an fp32 tensor)
+            const u32x4 r = *(const u32x4*)(addt16 + 1024 * nb);
+            ad[0] = pt16_lo(r);
+            ad[1] = pt16_hi(r);
+          }
+        }
         // 3. the slab's MFMAs
         f32x4 acc[kBlk];
 #pragma unroll
@@ -810,10 +854,22 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       const int FB = o.i0 >> 4;
       const float* t = pt_lane(o.p0, g, w, o.i0, o.i4);
       float dot = 0.f;
+      // bf16 instance: the operand may be a PT16 tensor (bf16 tiles): one 16-byte chunk per block pair
+      [[maybe_unused]] const bool is16 = BF16 && (o.flags & NPF_F_P16);
+      [[maybe_unused]] const unsigned short* t16 = is16 ? pt16_lane(o.p0, g, w, o.i0, o.i4) : (const unsigned short*)Z;
+      [[maybe_unused]] u32x4 r16 = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int b = 0; b < kMaxB16; ++b) {
         if (b < FB) {
           f32x4 v = zero4;
+          if constexpr (BF16) {
+            if (is16) {
+              if (!(b & 1) && w.valid) r16 = *(const u32x4*)(t16 + 1024 * (b >> 1));
+              v = (b & 1) ? pt16_hi(r16) : pt16_lo(r16);
+            } else if (w.valid) {
+              v = *(const f32x4*)(t + (4 * b + w.g) * 128);
+            }
+          } else
           if (w.valid) v = *(const f32x4*)(t + (4 * b + w.g) * 128);
           f32x4 c = cur[b];
 #pragma unroll
@@ -838,6 +894,17 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
     } else if (opc == NPF_OP_STORE_PT) {
       const int FB = o.i0 >> 4;
       float* t = (float*)pt_lane(o.p0, g, w, o.i0, o.i4);
+      if constexpr (BF16) {
+        if (o.flags & NPF_F_P16) {  // PT16 destination
+          unsigned short* t16 = (unsigned short*)pt16_lane(o.p0, g, w, o.i0, o.i4);
+          if (w.valid) {
+#pragma unroll
+            for (int st = 0; st < kMaxB16 / 2; ++st)
+              if (2 * st < FB) *(bf16x8*)(t16 + 1024 * st) = pack_bf16(cur[2 * st], cur[2 * st + 1]);
+          }
+          continue;
+        }
+      }
       if (w.valid) {
 #pragma unroll
         for (int b = 0; b < kMaxB16; ++b)
@@ -1060,6 +1127,7 @@ static int validate(const npf_program_t* g) {
   if (g->tiles_per_task != (g->pts_per_task + 31) / 32) return NPF_EINVAL;
   for (int i = 0; i < g->n_ops; ++i) {
     const npf_op_t& o = g->ops[i];
+    if ((o.flags & NPF_F_P16) && g->reserved[2] != 1) return NPF_EINVAL;  // PT16 operands: bf16 instance only
     switch (o.op) {
       case NPF_OP_LINEAR:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || o.i1 <= 0 || o.i1 > NPF_MAX_FEATURES || !o.p0) return NPF_EINVAL;

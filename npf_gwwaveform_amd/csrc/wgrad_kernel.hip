@@ -122,13 +122,18 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   const int n_split = J.first_wg[j + 1] - J.first_wg[j];
   const int Np = ((job.N + 31) >> 5) * 32, Kp = ((job.K + 31) >> 5) * 32;
   const long total_tiles = (long)J.n_tasks * J.tiles_per_task;
+  // A shared-weight job's tiles are dealt round-robin to its workgroups (tile split + n * n_split): the
+  // workgroups advance together, so at any time they read one contiguous region (all HBM channels) instead
+  // of n_split streams a fixed large stride apart.
   long t0, t1;
+  int tstride = 1;
   if (job.per_task) {
     t0 = (long)split * J.tiles_per_task;
     t1 = t0 + J.tiles_per_task;
   } else {
-    t0 = total_tiles * split / n_split;
-    t1 = total_tiles * (split + 1) / n_split;
+    t0 = split;
+    t1 = total_tiles;
+    tstride = n_split;
   }
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -190,10 +195,11 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
     }
   }
 
-  for (long t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) & 1);
+  int cur = 1;
+  for (long t = t0; t < t1; t += tstride) {
+    cur ^= 1;
     __syncthreads();  // vmcnt(0): tile t has landed; everyone is done with the other buffer
-    if (t + 1 < t1) tile_dma(t + 1, lds + (cur ^ 1) * 2 * kOp);
+    if (t + tstride < t1) tile_dma(t + tstride, lds + (cur ^ 1) * 2 * kOp);
     const unsigned boff = cur * 2 * kOp * 4;
     if constexpr (BF16) {
       if (act) {
@@ -344,10 +350,19 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
   }
   // workgroups per shared-weight job, proportional to its per-tile time: with the wave mapping
   // of wgrad_kernel a job with min(row blocks, column blocks) = b keeps b waves per SIMD busy
+  // (fp32 variant: the MFMAs set the tile time.)  The bf16 variant has 1/8 of the MFMA cycles and its tile
+  // time follows the bytes of the tile plus a latency floor (one tile in flight per workgroup): a skinny job
+  // costs almost as much per tile as a square one, and priced by its MFMAs it becomes the launch's critical path.
+  bool bf16 = true;
+  for (int j = 0; j < n_jobs; ++j) bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
   double cost[kMaxJobs], cost_sum = 0.0;
   for (int j = 0; j < n_jobs; ++j) {
-    const int ar = (npf::round_up(jobs[j].N, 32) + 63) / 64, ac = (npf::round_up(jobs[j].K, 32) + 63) / 64;
-    cost[j] = jobs[j].per_task ? 0.0 : (double)(ar < ac ? ar : ac) / 4.0;
+    const int Np = npf::round_up(jobs[j].N, 32), Kp = npf::round_up(jobs[j].K, 32);
+    const int ar = (Np + 63) / 64, ac = (Kp + 63) / 64;
+    if (jobs[j].per_task) cost[j] = 0.0;
+    else if (bf16)
+      cost[j] = 8192.0 + 32.0 * (Np * ((jobs[j].accumulate & NPF_WGRAD_DZ16) ? 2 : 4) + Kp * ((jobs[j].accumulate & NPF_WGRAD_A16) ? 2 : 4));
+    else cost[j] = (double)(ar < ac ? ar : ac) / 4.0;
     cost_sum += cost[j];
   }
   J->n_jobs = n_jobs;
