@@ -359,16 +359,40 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
   for (int j = 0; j < n_jobs; ++j) {
     const int Np = npf::round_up(jobs[j].N, 32), Kp = npf::round_up(jobs[j].K, 32);
     const int ar = (Np + 63) / 64, ac = (Kp + 63) / 64;
+    // cycles per tile: fp32 variant max(MFMA time of the busiest SIMD, tile bytes at ~6.5 B/clk per CU);
+    // bf16 variant: tile bytes with a floor (measured: a 4 KiB tile costs ~0.56 of a 32 KiB one)
+    const double zb = (jobs[j].accumulate & NPF_WGRAD_DZ16) ? 2.0 : 4.0, ab = (jobs[j].accumulate & NPF_WGRAD_A16) ? 2.0 : 4.0;
+    const double bytes = 32.0 * (Np * zb + Kp * ab);
     if (jobs[j].per_task) cost[j] = 0.0;
-    else if (bf16)
-      cost[j] = 8192.0 + 32.0 * (Np * ((jobs[j].accumulate & NPF_WGRAD_DZ16) ? 2 : 4) + Kp * ((jobs[j].accumulate & NPF_WGRAD_A16) ? 2 : 4));
-    else cost[j] = (double)(ar < ac ? ar : ac) / 4.0;
+    else if (bf16) cost[j] = bytes > 18432.0 ? bytes : 18432.0;
+    else {
+      const double mf = 4096.0 * (ar < ac ? ar : ac), mem = bytes / 6.5;
+      cost[j] = mf > mem ? mf : mem;
+    }
     cost_sum += cost[j];
   }
   J->n_jobs = n_jobs;
   J->n_tasks = n_tasks;
   J->tiles_per_task = tiles_per_task;
   J->pad = 0;
+  // floor: the shared-weight jobs of one launch must fit one wave of 256 workgroups (one per CU), a 257th
+  // workgroup would wait for a second round; what the floors leave over goes to the jobs one by one
+  long splits_of[kMaxJobs];
+  long used = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    splits_of[j] = 0;
+    if (jobs[j].per_task) continue;
+    long sp = (long)(256.0 * cost[j] / cost_sum);
+    if (sp < 1) sp = 1;
+    if (sp > total_tiles) sp = total_tiles;
+    splits_of[j] = sp;
+    used += sp;
+  }
+  for (int j = 0; j < n_jobs && used < 256; ++j)
+    if (!jobs[j].per_task && cost[j] * n_shared >= cost_sum && splits_of[j] < total_tiles) {  // (the costlier jobs)
+      ++splits_of[j];
+      ++used;
+    }
   int wg = 0;
   int64_t off = 0;
   for (int j = 0; j < n_jobs; ++j) {
@@ -379,11 +403,7 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
       wg += n_tasks;
     } else {
       const int Np = npf::round_up(jobs[j].N, 32), Kp = npf::round_up(jobs[j].K, 32);
-      // floor: the shared-weight jobs of one launch must fit one wave of 256 workgroups (one per
-      // CU), a 257th workgroup would wait for a second round
-      long splits = (long)(256.0 * cost[j] / cost_sum);
-      if (splits < 1) splits = 1;
-      if (splits > total_tiles) splits = total_tiles;
+      const long splits = splits_of[j];
       wg += (int)splits;
       off += (int64_t)splits * ((int64_t)Np * Kp + Np);
     }
