@@ -334,8 +334,8 @@ def main():
         roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
         if args.dtype == "bf16" and name == "chain_kernel":
-            # bf16 MLP layers are 16x shorter than their fp32 form while the saved activations are still
-            # fp32 tensors: these launches are bound by HBM, priced by their algorithmic bytes
+            # bf16 MLP layers have 1/16 of the MFMA cycles of their fp32 form: these launches are priced
+            # against HBM by their algorithmic bytes (PT16 tensors counted at 2 bytes per value)
             gbps = nb / sec * 1e-9
             roofline = {"kernel": name, "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": gbps / PEAK_HBM_GBPS, "traffic": None, "achieved_tflops_algorithmic": ach}
@@ -371,7 +371,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 (MLP-stack MFMAs; attention, accumulation, weight gradients f32)",
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
                 "workload": f"BASELINE config {2 if args.dtype == 'fp32' else 3}: {'AttnCNP' if args.model == 'attncnp' else 'AttnLNP(is_q_zCct, n_z=1)'} "

@@ -50,6 +50,27 @@ def chain_case(name, n_tasks, pts, layers, store=False, relu=True, per_task=Fals
     report(name, prog.flops(), timeit(prog._launch))
 
 
+def chain_case_bf16(name, n_tasks, pts, layers, store=None, relu=True):
+    """bf16 compute mode; store: None (last layer only), "pt32" or "pt16" (every layer, as a training forward)."""
+    CH.set_compute_dtype("bf16")
+    K0 = layers[0][0]
+    x = torch.randn(CH.pt_shape(n_tasks, pts, K0), device=DEV)
+    imgs = [CH.cast_bf16_weights(torch.randn(N, K, device=DEV) / math.sqrt(K)) for K, N in layers]
+    bs = [torch.randn(N, device=DEV) * 0.1 for K, N in layers]
+    mk = CH.pt16_empty if store == "pt16" else CH.pt_empty
+    bufs = [mk(n_tasks, pts, N, DEV) for K, N in layers]
+    prog = CH.Program(n_tasks, pts, False)
+    prog.load_pt(x, K0)
+    for (K, N), img, b, buf in zip(layers, imgs, bs, bufs):
+        prog.linear_bf16(img, K, N, bias=b, relu=relu)
+        if store:
+            prog.store_pt(buf, N)
+    if not store:
+        prog.store_pt(bufs[-1], layers[-1][1])
+    report(name, prog.flops(), timeit(prog._launch))
+    CH.set_compute_dtype("fp32")
+
+
 def attn_case(name, B, C, T, r):
     q = torch.randn(CH.pt_shape(B, T, r), device=DEV)
     k = torch.randn(CH.pt_shape(B, C, r), device=DEV)
@@ -98,6 +119,14 @@ if __name__ == "__main__":
         chain_case("32->256 then 7 x 256->256", B, T, [(32, 256)] + [(256, 256)] * 7)
         chain_case("8 x [256->32]", B, T, [(256, 32), (32, 256)] * 4)
         chain_case("8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+    if "bf16" in which:
+        chain_case_bf16("bf16 8 x linear 256->256, store last", 1024, T, [(256, 256)] * 8)
+        chain_case_bf16("bf16 8 x linear 256->256, store every layer (PT16)", 1024, T, [(256, 256)] * 8, store="pt16")
+        chain_case_bf16("bf16 8 x linear 256->256, store every layer (PT32)", 1024, T, [(256, 256)] * 8, store="pt32")
+        for bits, name in [(16, "generic loop"), (17, "generic, no slab DMA"), (24, "generic, no MFMA"), (20, "generic, no barrier")]:
+            CH.DEBUG_ABLATE = bits
+            chain_case_bf16(f"bf16 ablate[{name}] 8 x linear 256->256", 1024, T, [(256, 256)] * 8)
+        CH.DEBUG_ABLATE = 0
     if "decode" in which:
         # BASELINE config 5 per GPU: decoder r=512, L=4, T=4096, 512 tasks (4096 / 8 GPUs)
         chain_case("decode c5: 6 x 512->512 + 512->4, B=128 T=4096", 128, 4096, [(512, 512)] * 6 + [(512, 4)])
