@@ -343,10 +343,13 @@ def main():
         # separate rocprofv3 --pmc passes of this same command), condensed by
         # tools/summarize_profiles.py into profiles/<round>_summary.json
         import glob
+        profiled = {"fp32": (256, 256, 1024, 256), "bf16": (1024, 256, 1024, 256)}[args.dtype]  # the shapes the PMC passes ran
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+            if ("bf16" in os.path.basename(f)) != (args.dtype == "bf16"):
+                continue
             try:
                 k = json.load(open(f))["kernels"].get("npf::" + name)
-                if k and "hbm_bytes_per_launch" in k and (args.batch, C, T, args.r, args.dtype) == (256, 256, 1024, 256, "fp32"):
+                if k and "hbm_bytes_per_launch" in k and (B, C, T, args.r) == profiled and args.workload == "train":
                     roofline["traffic"] = k["hbm_bytes_per_launch"]
                     roofline["traffic_unit"] = "bytes/launch"
                     roofline["traffic_source"] = os.path.relpath(f, ROOT)
