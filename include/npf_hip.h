@@ -163,7 +163,7 @@ typedef struct npf_wgrad_job {
 } npf_wgrad_job_t;
 #define NPF_WGRAD_ACCUMULATE 1
 #define NPF_WGRAD_BF16 2
-#define NPF_WGRAD_DZ16 4 /* with NPF_WGRAD_BF16: dZ is a PT16 tensor (bf16 tiles, see NPF_OP_STORE_PT16) */
+#define NPF_WGRAD_DZ16 4 /* with NPF_WGRAD_BF16: dZ is a PT16 tensor (bf16 tiles, see NPF_F_P16) */
 #define NPF_WGRAD_A16 8  /* with NPF_WGRAD_BF16: A is a PT16 tensor */
 
 #define NPF_MAX_WGRAD_JOBS 16

@@ -119,6 +119,9 @@ if __name__ == "__main__":
         chain_case("32->256 then 7 x 256->256", B, T, [(32, 256)] + [(256, 256)] * 7)
         chain_case("8 x [256->32]", B, T, [(256, 32), (32, 256)] * 4)
         chain_case("8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+    if "bf16q" in which:
+        chain_case_bf16("bf16 8 x linear 256->256, store last", 1024, T, [(256, 256)] * 8)
+        chain_case("fp32 8 x linear 256->256, relu, store last", B, T, [(256, 256)] * 8)
     if "bf16" in which:
         chain_case_bf16("bf16 8 x linear 256->256, store last", 1024, T, [(256, 256)] * 8)
         chain_case_bf16("bf16 8 x linear 256->256, store every layer (PT16)", 1024, T, [(256, 256)] * 8, store="pt16")
