@@ -64,6 +64,45 @@ def test_invalid_programs_are_rejected_without_launching():
     assert lib.npf_gauss_head_fwd(None, 1, 1, 1, 0, None, 0, None, None, None, None) == -1
 
 
+def test_wgrad_job_split_fills_one_round_of_workgroups():
+    """npf_wgrad_partials_bytes runs the launcher's host-side plan: the shared-weight jobs of a launch share
+    256 workgroups (one per CU) in proportion to a per-tile cost, every job gets at least one, and a skinny
+    job of the bf16 variant is priced by its bytes (not by its MFMAs: it would become the critical path)."""
+    from npf_gwwaveform_amd import _lib
+
+    lib = _lib.load()
+
+    def splits(shapes, flags=0, n_tasks=64, tiles=32):
+        """workgroups per job, recovered from the partial-slab bytes of one-job-at-a-time differences"""
+        arr = (_lib.NpfWgradJob * len(shapes))()
+        for j, (N, K) in enumerate(shapes):
+            arr[j].dZ = arr[j].A = arr[j].dW = 4096  # (never dereferenced by the plan)
+            arr[j].N, arr[j].K, arr[j].ldw, arr[j].accumulate = N, K, K, flags
+        total = lib.npf_wgrad_partials_bytes(arr, len(shapes), n_tasks, tiles)
+        assert total > 0
+        return total
+
+    pad = lambda v: (v + 31) // 32 * 32  # noqa: E731
+    slab = lambda N, K: 4 * (pad(N) * pad(K) + pad(N))  # noqa: E731
+    # identical jobs: all 256 workgroups are handed out
+    assert (splits([(256, 256)] * 7) - 16) == 256 * slab(256, 256)
+    assert (splits([(256, 256)] * 6, flags=2) - 16) == 256 * slab(256, 256)
+    # one job alone never gets more workgroups than tiles
+    assert (splits([(64, 64)], n_tasks=2, tiles=3) - 16) == 6 * slab(64, 64)
+    # bf16 variant, 256x256 + skinny 4x256: the skinny job's share follows its tile bytes, 36 KiB of 64 + 36 KiB
+    b = splits([(256, 256), (4, 256)], flags=2) - 16
+    n_skinny = (256 * slab(256, 256) - b) // (slab(256, 256) - slab(4, 256))
+    assert 85 <= n_skinny <= 100, n_skinny
+    # fp32 variant: priced by MFMA time (1 of 4 wave rows busy) or bytes, whichever is larger: fewer workgroups
+    f = splits([(256, 256), (4, 256)], flags=0) - 16
+    n_skinny32 = (256 * slab(256, 256) - f) // (slab(256, 256) - slab(4, 256))
+    assert 55 <= n_skinny32 <= 75, n_skinny32
+    # invalid jobs are refused
+    bad = (_lib.NpfWgradJob * 1)()
+    bad[0].N, bad[0].K = 300, 8
+    assert lib.npf_wgrad_partials_bytes(bad, 1, 4, 4) < 0
+
+
 def _model(kind, **kw):
     import npf_gwwaveform_amd as A
 
