@@ -28,6 +28,7 @@ PROFILE = None
 DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microbench.py)
 # tests / tools: 1 = 64-point workgroups, 2 = 128-point (paired) workgroups, 0 = the library's choice
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
+PT16_INTERNAL = os.environ.get("NPF_NO_PT16", "0") != "1"  # bf16 mode: backward-only tensors as bf16 tiles (debug switch)
 
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
@@ -541,7 +542,7 @@ class _ChainFn(torch.autograd.Function):
             """A tensor holding cur: an fp32 PT32 tensor (required for outputs and for operands of fp32-only
             consumers), or -- bf16 mode, ``internal`` -- a PT16 tensor at half the HBM traffic."""
             nonlocal backed, backed16
-            if internal and bf16 and backed is None:
+            if internal and bf16 and PT16_INTERNAL and backed is None:
                 if backed16 is None:
                     backed16 = pt16_empty(chain.n_tasks, chain.pts, F, dev)
                     prog.store_pt(backed16, F)
@@ -684,7 +685,7 @@ class _ChainFn(torch.autograd.Function):
         def new_pt(F, internal=False):
             """Gradient buffer: fp32 PT32 when it is returned to autograd or reduced by an fp32 kernel; in the bf16
             mode a PT16 tensor when it only feeds the wgrad kernel (``internal``)."""
-            if internal and ctx.bf16:
+            if internal and ctx.bf16 and PT16_INTERNAL:
                 return pt16_empty(chain.n_tasks, chain.pts, F, dev)
             return pt_empty(chain.n_tasks, chain.pts, F, dev)
 
