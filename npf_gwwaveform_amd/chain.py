@@ -212,10 +212,11 @@ class Program:
         if not ok:
             raise ValueError(f"bad bf16 weight image {tuple(W_img.shape)} {W_img.dtype} for a {K}->{N} layer")
         self.bf16 = True
-        flags = (L.F_RELU if relu else 0) | (L.F_ADD_PT if addend is not None else 0)
+        p_add, fl_add = self._pt(addend) if addend is not None else (None, 0)  # (fp32 PT32 or PT16)
+        flags = (L.F_RELU if relu else 0) | ((L.F_ADD_PT | fl_add) if addend is not None else 0)
         self.keep.append(W_img)
         self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=L.W_ROWMAJOR, i3=pad32(K) // 2, flags=flags, i4=addend_modulus,
-                 p0=W_img.data_ptr(), p1=self._p(bias), p2=self._p(addend),
+                 p0=W_img.data_ptr(), p1=self._p(bias), p2=p_add,
                  s0=(W_img.shape[1] * pad32(K) // 2 if per_task else 0), s1=b_task_stride)
 
     def store_wb(self, img, F):

@@ -341,6 +341,65 @@ def _pack_pt16_reference(x):
     return v.view(B, tiles, Fp // 8, 32, 8).to(torch.bfloat16)
 
 
+def _unpack_pt16_reference(t, P, F):
+    """PT16 tensor -> row-major [B, P, F] float (inverse of _pack_pt16_reference)."""
+    B, tiles, rows, _, _ = t.shape
+    Fp = rows * 8
+    v = t.float().cpu().view(B, tiles, Fp // 32, 4, 32, 2, 4).permute(0, 1, 4, 2, 5, 3, 6).contiguous()
+    return v.view(B, tiles * 32, Fp)[:, :P, :F]
+
+
+def test_pt16_operands_of_the_chain_ops():
+    """NPF_F_P16 on every chain op that takes it (bf16 instance): LOAD_PT, a LINEAR's addend (generic slab loop:
+    a PT16 addend keeps a layer off the pipelined path) and its fused relu-backward mask (pipelined path at
+    256 -> 256), ADD_PT (+relu), MASK_POS, ROWDOT_PT + SOFTMAX_BWD, STORE_PT -- against the same operations on the
+    bf16-rounded tensors."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(51)
+    for n_tasks, pts, K, N in ((2, 70, 256, 256), (3, 45, 64, 100), (1, 33, 32, 256)):
+        x, a1, a2, m = (torch.randn(n_tasks, pts, f, generator=g) for f in (K, N, N, N))
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) * 0.1
+        r = _bf16_round
+        lin = r(x).double() @ r(W).double().t() + b.double()
+        y1 = torch.relu(torch.relu(lin + r(a1).double()) + r(a2).double())     # addend, then add_pt with relu
+        y2 = torch.where(r(m) > 0, lin, torch.zeros_like(lin))                  # fused mask
+        y3 = torch.where(r(m) > 0, y1, torch.zeros_like(y1))                    # mask_pos as its own op
+        P_ = torch.softmax(torch.randn(n_tasks, pts, N, generator=g), -1)
+        y4 = 0.5 * r(P_).double() * (lin - (lin * r(P_).double()).sum(-1, keepdim=True))  # softmax backward
+        x16, a16, b16, m16, p16 = (_pack_pt16_reference(t).to(DEV) for t in (x, a1, a2, m, P_))
+        img = CH.cast_bf16_weights(W.to(DEV))
+        outs = []
+        for variant in range(4):
+            prog = CH.Program(n_tasks, pts, False)
+            prog.load_pt(x16, K)
+            if variant == 0:
+                prog.linear_bf16(img, K, N, bias=b.to(DEV), relu=True, addend=a16)
+                prog.add_pt(b16, N, relu=True)
+            elif variant == 1:
+                prog.linear_bf16(img, K, N, bias=b.to(DEV))
+                prog.mask_pos(m16, N)                       # (fuses into the layer above)
+            elif variant == 2:
+                prog.linear_bf16(img, K, N, bias=b.to(DEV), relu=True, addend=a16)
+                prog.add_pt(b16, N, relu=True)
+                prog.mask_pos(m16, N)                       # (the layer has an addend: stays its own op)
+            else:
+                prog.linear_bf16(img, K, N, bias=b.to(DEV))
+                prog.rowdot_pt(p16, N)
+                prog.softmax_bwd(p16, N, 0.5)
+            o16 = CH.pt16_empty(n_tasks, pts, N, DEV)
+            o32 = CH.pt_empty(n_tasks, pts, N, DEV)
+            prog.store_pt(o16, N)
+            prog.store_pt(o32, N)
+            prog.launch()
+            outs.append((o16, o32))
+        for (o16, o32), ref, what in zip(outs, (y1, y2, y3, y4), ("addend + add_pt", "fused mask", "mask_pos", "softmax bwd")):
+            got32 = FN.unpack_pt(o32, pts, N)
+            assert_close(got32, ref, tol=2e-3, what=f"pt16 {what} {K}->{N}")
+            # the PT16 store is the bf16 rounding of the fp32 store, element for element
+            assert torch.equal(_unpack_pt16_reference(o16, pts, N), got32.cpu().to(torch.bfloat16).float()), what
+
+
 def test_bf16_wgrad_with_pt16_operands():
     """wgrad kernel, bf16 variant, with one or both operands given as PT16 tensors (bf16 tiles): same result
     as with the fp32 tiles of the same bf16-rounded values."""
