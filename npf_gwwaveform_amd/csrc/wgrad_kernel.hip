@@ -53,57 +53,71 @@ __device__ __forceinline__ bf16x4 pack4_bf16(float a, float b, float c, float d)
   return r;
 }
 
-// The four bf16x4 operands (features m = 0..3 of this lane's row, 4 consecutive points each) of one 16-point
-// step, from an fp32 tile image (lane row = quad row 16 blk + i: 4 x ds_read_b128, rounded here) or from a
-// PT16 tile image (lane row = half h = i >> 3 of the 8-feature row 8 blk + (i & 7): 4 x ds_read_b64, the
-// 16-bit values regrouped with v_perm).  `dsum`: accumulates the sum over the points (bias gradient).
+// The four bf16x4 operands of one 16-point step (MFMA lane i = one feature, its 4 k-slots = the 4 consecutive
+// points 16 t2 + 4 g .. + 3) of the wave's 64-feature block `blk`, and which feature that is:
+//   fp32 tile image: lane i = quad row 16 blk + i, operand m = feature 4 (16 blk + i) + m:
+//     4 x ds_read_b128 (one per point), rounded here with v_cvt_pk_bf16_f32;
+//   PT16 tile image ([F/8 rows][32 points][8 bf16], row 4 s + gg = features {32 s + 4 gg + j}, {32 s + 16 + 4 gg + j}):
+//     one ds_read_b64_tr_b16 per operand -- the hardware transpose turns 4 points x 16 features (lane 4 q + p of a
+//     16-lane group supplies point q, the 8 bytes = 4 features of column group p) into "lane c holds feature c at
+//     the 4 points".  The 16 features of operand m are {32 s + 16 h + 4 m + j}: s in {s0, s0 + 2}, h, j -- rows
+//     4 s0 + m and 4 (s0 + 2) + m differ in bit 3 of the row swizzle, which makes the read bank-conflict free
+//     (32 lanes, 32 distinct bank pairs); the block owns s0 = 4 (blk >> 1) + (blk & 1) and s0 + 2.
+// `want_sum`: `dsum` accumulates the sum over the points (bias gradient), element m = the lane's feature of operand m.
+__device__ __forceinline__ int wg_s0(int blk) { return 4 * (blk >> 1) + (blk & 1); }
+
 __device__ __forceinline__ void operand16(const float* img, bool fmt16, int blk, int i, int g, int t2, bf16x4 (&op)[4],
-                                          f32x4* dsum) {
+                                          bool want_sum, f32x4& dsum) {
   if (!fmt16) {
+    // (inline asm, here and below: a C++ LDS load after the tile DMA was issued makes hipcc wait for vmcnt(0)
+    // first -- it cannot tell the two LDS buffers apart -- and the double buffering is gone)
     f32x4 q[4];
+    const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)img + (16 * blk + i) * 512;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int c = 16 * t2 + 4 * g + jj;
-      q[jj] = *(const f32x4*)(img + (16 * blk + i) * 128 + ((c ^ i) << 2));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(q[jj]) : "v"(lbase + ((c ^ i) << 4)));
     }
-    if (dsum) *dsum += (q[0] + q[1]) + (q[2] + q[3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    if (want_sum) dsum += (q[0] + q[1]) + (q[2] + q[3]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) op[m] = pack4_bf16(q[0][m], q[1][m], q[2][m], q[3][m]);
   } else {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const int o = 8 * blk + (i & 7), h = i >> 3;
-    u32x2 q[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int c = 16 * t2 + 4 * g + jj;
-      q[jj] = *(const u32x2*)(img + o * 128 + ((c ^ (o & 15)) << 2) + 2 * h);
-    }
-    if (dsum) {
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        (*dsum)[0] += __builtin_bit_cast(float, q[jj][0] << 16);
-        (*dsum)[1] += __builtin_bit_cast(float, q[jj][0] & 0xffff0000u);
-        (*dsum)[2] += __builtin_bit_cast(float, q[jj][1] << 16);
-        (*dsum)[3] += __builtin_bit_cast(float, q[jj][1] & 0xffff0000u);
-      }
-    }
+    const int q = i >> 2, p = i & 3;
+    const int row0 = 4 * (wg_s0(blk) + 2 * (p >> 1));  // + m
+    const int point = 16 * t2 + 4 * g + q;
+    const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)img + 8u * (p & 1);
+    u32x2 r[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int w = m >> 1;
-      const unsigned sel = (m & 1) ? 0x07060302u : 0x05040100u;  // the high / low 16 bits of the two sources
-      u32x2 r;
-      r[0] = __builtin_amdgcn_perm(q[1][w], q[0][w], sel);
-      r[1] = __builtin_amdgcn_perm(q[3][w], q[2][w], sel);
-      op[m] = __builtin_bit_cast(bf16x4, r);
+      const int row = row0 + m;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r[m]) : "v"(base + row * 512 + ((point ^ (row & 15)) << 4)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      op[m] = __builtin_bit_cast(bf16x4, r[m]);
+    }
+    if (want_sum) {
+      f32x4 sm;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        sm[m] = (__builtin_bit_cast(float, r[m][0] << 16) + __builtin_bit_cast(float, r[m][0] & 0xffff0000u)) +
+                (__builtin_bit_cast(float, r[m][1] << 16) + __builtin_bit_cast(float, r[m][1] & 0xffff0000u));
+      dsum += sm;
     }
   }
 }
 
-// Feature index of (64-feature block, operand lane row i, element m) for the two tile formats.
+// Feature index of (64-feature block, operand lane i, operand m) for the two tile formats.
 __device__ __forceinline__ int wg_feature(bool fmt16, int blk, int i, int m) {
   if (!fmt16) return 4 * (16 * blk + i) + m;
-  const int o = 8 * blk + (i & 7);
-  return 32 * (o >> 2) + 16 * (i >> 3) + 4 * (o & 3) + m;
+  return 32 * (wg_s0(blk) + 2 * (i >> 3)) + 16 * ((i >> 2) & 1) + 4 * m + (i & 3);
+}
+// Does block `blk` hold any feature < Fp (Fp a multiple of 32)?
+__device__ __forceinline__ bool wg_block_active(bool fmt16, int blk, int Fp) {
+  return fmt16 ? 32 * wg_s0(blk) < Fp : 64 * blk < Fp;
 }
 
 // BF16: the same contraction with the operands rounded to bf16 at the MFMA input
@@ -145,7 +159,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   const bool wide_rows = ((Kp + 63) >> 6) < ((Np + 63) >> 6);
   const int rg = wide_rows ? (wave & 3) : (wave >> 2);
   const int cg = wide_rows ? (wave >> 2) : (wave & 3);
-  const bool act = (64 * rg < Np) && (64 * cg < Kp);
+  const bool act = wg_block_active(BF16 && (job.accumulate & NPF_WGRAD_DZ16) != 0, rg, Np) &&
+                   wg_block_active(BF16 && (job.accumulate & NPF_WGRAD_A16) != 0, cg, Kp);
 
   // zero the LDS once: quad rows beyond Np/4, Kp/4 are never written and must read as zero
   for (int x = tid; x < 2 * 2 * kOp; x += kWgThreads) lds[x] = 0.f;
@@ -209,8 +224,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
         for (int t2 = 0; t2 < 2; ++t2) {
           // points 16 t2 + 4 g + j, j < 4: chunk c of row r lives at chunk position c ^ (r & 15)
           bf16x4 am[4], bn[4];
-          operand16(zimg, z16, rg, i, g, t2, am, cg == 0 ? &dbacc : nullptr);
-          operand16(aimg, a16, cg, i, g, t2, bn, nullptr);
+          f32x4 none = zero4;
+          // (the fragment addresses are recomputed per tile from an opaque copy of the lane ids: hoisted out of the
+          // loop they spill, and a spill reload waits on vmcnt -- i.e. on the tile DMA that was just issued)
+          int iv = i, gv = g;
+          asm volatile("" : "+v"(iv), "+v"(gv));
+          operand16(zimg, z16, rg, iv, gv, t2, am, cg == 0, dbacc);
+          operand16(aimg, a16, cg, iv, gv, t2, bn, false, none);
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -248,8 +268,12 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 
   // ---- write out --------------------------------------------------------------------
   // acc[m][n][e] on lane (i, g) = D[row 4*(16rg + 4g + e) + m][col 4*(16cg + i) + n]
+  // (fp32 tile format: the columns n = 0..3 of a lane are 4 consecutive features, one 16-byte store; PT16 format:
+  // features 4 apart, scalar stores -- once per workgroup)
   if (act) {
-    const int col = wg_feature(a16, cg, i, 0);  // (the 4 values n = 0..3 are the next 4 features in both formats)
+    int col[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) col[n] = wg_feature(a16, cg, i, n);
     if (job.per_task) {
       // PT32 tensor, points = row index (n of dW), features = column index (k)
       float* out = job.dW + (size_t)split * ((Np >> 5) * Kp * 32);
@@ -258,13 +282,24 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = wg_feature(z16, rg, 4 * g + e, m);
-          if (row < Np && col < Kp) {
-            f32x4 v;
+          if (row >= Np) continue;
+          float* rbase = out + (size_t)(row >> 5) * (Kp >> 2) * 128 + (row & 31) * 4;
+          if (!a16) {
+            if (col[0] < Kp) {
+              f32x4 v;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
-            float* dst = out + ((size_t)(row >> 5) * (Kp >> 2) + (col >> 2)) * 128 + (row & 31) * 4;
-            if (job.accumulate & NPF_WGRAD_ACCUMULATE) v += *(const f32x4*)dst;
-            *(f32x4*)dst = v;
+              for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
+              float* dst = rbase + (size_t)(col[0] >> 2) * 128;
+              if (job.accumulate & NPF_WGRAD_ACCUMULATE) v += *(const f32x4*)dst;
+              *(f32x4*)dst = v;
+            }
+          } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              if (col[n] < Kp) {
+                float* dst = rbase + (size_t)(col[n] >> 2) * 128 + (col[n] & 3);
+                *dst = (job.accumulate & NPF_WGRAD_ACCUMULATE) ? *dst + acc[m][n][e] : acc[m][n][e];
+              }
           }
         }
     } else {
@@ -274,21 +309,36 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = wg_feature(z16, rg, 4 * g + e, m);
-          if (row < Np && col < Kp) {
-            f32x4 v;
+          if (row >= Np) continue;
+          if (!a16) {
+            if (col[0] < Kp) {
+              f32x4 v;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
-            *(f32x4*)(part + (size_t)row * Kp + col) = v;
+              for (int n = 0; n < 4; ++n) v[n] = acc[m][n][e];
+              *(f32x4*)(part + (size_t)row * Kp + col[0]) = v;
+            }
+          } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              if (col[n] < Kp) part[(size_t)row * Kp + col[n]] = acc[m][n][e];
           }
         }
       if (cg == 0) {
-        // dbacc[m] on lane (i, g): sum over the points = g (mod 4) of feature 4*(16rg+i)+m
+        // dbacc[m] on lane (i, g): sum over the points = g (mod 4) of the lane's feature of operand m
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           dbacc[m] += __shfl_xor(dbacc[m], 16);
           dbacc[m] += __shfl_xor(dbacc[m], 32);
         }
-        if (g == 0 && wg_feature(z16, rg, i, 0) < Np) *(f32x4*)(part + (size_t)Np * Kp + wg_feature(z16, rg, i, 0)) = dbacc;
+        if (g == 0) {
+          if (!z16) {
+            if (wg_feature(false, rg, i, 0) < Np) *(f32x4*)(part + (size_t)Np * Kp + wg_feature(false, rg, i, 0)) = dbacc;
+          } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              if (wg_feature(true, rg, i, m) < Np) part[(size_t)Np * Kp + wg_feature(true, rg, i, m)] = dbacc[m];
+          }
+        }
       }
     }
   }

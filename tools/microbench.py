@@ -107,6 +107,27 @@ def wgrad_case(name, n_tasks, pts, shapes, per_task=False):
     report(name, fl, timeit(lambda: CH._run_wgrad(jobs, n_tasks, pts, DEV)))
 
 
+def wgrad_case_bf16(name, n_tasks, pts, shapes, pt16=True):
+    """bf16 wgrad variant; operands PT16 (bf16 tiles) or fp32 PT32."""
+    CH.set_compute_dtype("bf16")
+    mk = (lambda F: torch.randn(CH.pt16_shape(n_tasks, pts, F), device=DEV).to(torch.bfloat16)) if pt16 else \
+         (lambda F: torch.randn(CH.pt_shape(n_tasks, pts, F), device=DEV))
+    ops = {}
+    jobs = []
+    for N, K in shapes:
+        dz, a = ops.setdefault(("z", N), mk(N)), ops.setdefault(("a", K), mk(K))
+        jobs.append(dict(dZ=dz, A=a, N=N, K=K, dW=torch.empty(N, K, device=DEV), db=torch.empty(N, device=DEV)))
+    fl = sum(2 * N * K for N, K in shapes) * n_tasks * pts
+    sec = timeit(lambda: CH._run_wgrad(jobs, n_tasks, pts, DEV))
+    nbytes = sum((pad(N) + pad(K)) * (2 if pt16 else 4) for N, K in shapes) * n_tasks * pts
+    report(name + f"  [{nbytes / sec * 1e-12:.2f} TB/s]", fl, sec)
+    CH.set_compute_dtype("fp32")
+
+
+def pad(v):
+    return (v + 31) // 32 * 32
+
+
 if __name__ == "__main__":
     B, T, C = 256, 1024, 256
     which = sys.argv[1:] or ["chain", "attn", "wgrad"]
@@ -119,6 +140,10 @@ if __name__ == "__main__":
         chain_case("32->256 then 7 x 256->256", B, T, [(32, 256)] + [(256, 256)] * 7)
         chain_case("8 x [256->32]", B, T, [(256, 32), (32, 256)] * 4)
         chain_case("8 x linear 256->256 (ctx-sized grid)", B, C, [(256, 256)] * 8)
+    if "wgbf16" in which:
+        wgrad_case_bf16("bf16 wgrad 7 jobs 256x256, PT16 operands, 1M points", 1024, T, [(256, 256)] * 7)
+        wgrad_case_bf16("bf16 wgrad 7 jobs 256x256, fp32 operands, 1M points", 1024, T, [(256, 256)] * 7, pt16=False)
+        wgrad_case_bf16("bf16 wgrad 1 job 256x256, PT16 operands, 1M points", 1024, T, [(256, 256)])
     if "bf16q" in which:
         chain_case_bf16("bf16 8 x linear 256->256, store last", 1024, T, [(256, 256)] * 8)
         chain_case("fp32 8 x linear 256->256, relu, store last", B, T, [(256, 256)] * 8)
