@@ -776,18 +776,8 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
       // cache) and no dynamically indexed register array is needed.
       for (int nb = 0; nb < NB; ++nb) {
-        if (!grp_b) NPF_STAMP(4)  // (group A) loop back-edge
-        // 1. start filling the other slot with the next slab (possibly the next layer's)
-        if (pf.op < g.n_ops) {
-          const int nslot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
-          SlabDma d = dma_begin(pfs, pf.nb, w, smem + nslot * kSlabFloats, !(g.reserved[0] & 1));
-          NPF_STAMP(6)  // loop top
-          dma_finish(pfs, d, w);
-          NPF_STAMP(0)  // DMA pieces
-          advance();
-          NPF_STAMP(7)  // cursor advance (+ next layer's slab constants)
-        }
-        // 2. addend tiles (consumed after the barrier)
+        // 1. addend tiles (consumed after the barrier).  Before the slab DMA: hipcc guards the reuse of the
+        // addend registers with a full vmcnt drain, which must not include the DMA issued for the next slab
         f32x4 ad[kBlk];
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) ad[j] = *(const f32x4*)(addt + (4 * kBlk * nb + 4 * j + w.g) * astep);
@@ -797,6 +787,17 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
             ad[0] = pt16_lo(r);
             ad[1] = pt16_hi(r);
           }
+        }
+        // 2. start filling the other slot with the next slab (possibly the next layer's)
+        if (!grp_b) NPF_STAMP(4)  // (group A) loop back-edge; (without stamps: the statement below is its body)
+        if (pf.op < g.n_ops) {
+          const int nslot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+          SlabDma d = dma_begin(pfs, pf.nb, w, smem + nslot * kSlabFloats, !(g.reserved[0] & 1));
+          NPF_STAMP(6)  // loop top
+          dma_finish(pfs, d, w);
+          NPF_STAMP(0)  // DMA pieces
+          advance();
+          NPF_STAMP(7)  // cursor advance (+ next layer's slab constants)
         }
         // 3. the slab's MFMAs
         f32x4 acc[kBlk];
