@@ -510,6 +510,9 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 //     the bias piece of slab I+1
 //   barrier (slab I consumed by the workgroup, slab I+1 landed).
 // EPI: 0 = out + addend, 1 = relu(out + addend), 2 = addend > 0 ? out : 0.
+#ifndef NPF_DMA_KB0
+#define NPF_DMA_KB0 0  // k-block of the stage's first DMA piece
+#endif
 template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class NextLayer>
 __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
                                            f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
@@ -573,10 +576,10 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
       if (I < NB - 1 && (!PAIRED || issuer)) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i)
-          if (kb == (E + 1 + i < KB16S - 1 ? E + 1 + i : KB16S - 1))
+          if (kb == (NPF_DMA_KB0 + i < KB16S - 1 ? NPF_DMA_KB0 + i : KB16S - 1))
             dma16_so(src + (size_t)(i * op.step) * 4, op.lo[i & 7], nslot + w.wave * 256 + i * (kWaves * 256));
         // (every issuing wave writes the same 32 biases: no wave-dependent branch in this loop)
-        if (kb == (E + 1 + NPW < KB16S - 1 ? E + 1 + NPW : KB16S - 1))
+        if (kb == (NPF_DMA_KB0 + NPW < KB16S - 1 ? NPF_DMA_KB0 + NPW : KB16S - 1))
           dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, nslot + kSlabRows * Kp);
       }
     });
