@@ -122,8 +122,9 @@ __device__ __forceinline__ bool wg_block_active(bool fmt16, int blk, int Fp) {
 
 // BF16: the same contraction with the operands rounded to bf16 at the MFMA input
 // (v_mfma_f32_16x16x16_bf16, fp32 accumulation): the k-slots of a lane group are 4 consecutive points, so
-// a lane reads its quad row at 4 points (4 x ds_read_b128 per operand) and forms the 4 + 4 operands of
-// the 16 (m, m') MFMAs of a 16-point step; 2 steps per tile instead of 8 -- the kernel becomes HBM-bound.
+// a lane reads its quad row at 4 points (fp32 tiles: 4 x ds_read_b128 per operand; PT16 tiles: 4 transposing
+// reads, see operand16) and forms the 4 + 4 operands of the 16 (m, m') MFMAs of a 16-point step; 2 steps per
+// tile instead of 8 -- HBM traffic (4 TB/s measured with PT16 operands), not the MFMAs, then sets the pace.
 template <bool BF16>
 __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J, float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kQRows * 128];  // 2 buffers x (dZ, A)
