@@ -195,8 +195,20 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
       wg_dma16((const float*)(asrc + (size_t)q * 1024 + (size_t)dma_lane), buf + kOp + q * 256);
   };
 
+  // Both operands PT16: a tile pair fits one buffer (each image is half of kOp), and two tiles go through
+  // every barrier: the bytes in flight per workgroup of the fp32 tiles (one 32 KiB pair in flight per
+  // workgroup is latency-bound at ~4 TB/s).
+  [[maybe_unused]] const bool dual = z16 && a16;
+  const long tstep = (BF16 && dual) ? 2 * (long)tstride : (long)tstride;
+  auto step_dma = [&](long t, float* buf) {  // the tile(s) of one pipeline step
+    tile_dma(t, buf);
+    if constexpr (BF16) {
+      if (dual && t + tstride < t1) tile_dma(t + tstride, buf + kOp / 2);
+    }
+  };
+
   __syncthreads();
-  if (t0 < t1) tile_dma(t0, lds);
+  if (t0 < t1) step_dma(t0, lds);
 
   // fragment addresses: chunk (4 s + g) ^ i of quad row (base + i); with s = 4 m + t the lane
   // part only depends on t (4 address registers per operand, m goes to the immediate offset)
@@ -212,14 +224,16 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   }
 
   int cur = 1;
-  for (long t = t0; t < t1; t += tstride) {
+  for (long t = t0; t < t1; t += tstep) {
     cur ^= 1;
     __syncthreads();  // vmcnt(0): tile t has landed; everyone is done with the other buffer
-    if (t + tstride < t1) tile_dma(t + tstride, lds + (cur ^ 1) * 2 * kOp);
-    const unsigned boff = cur * 2 * kOp * 4;
+    if (t + tstep < t1) step_dma(t + tstep, lds + (cur ^ 1) * 2 * kOp);
+    [[maybe_unused]] const unsigned boff = cur * 2 * kOp * 4;
     if constexpr (BF16) {
-      if (act) {
-        const float* zimg = lds + cur * 2 * kOp;
+      const int nsub = (dual && t + tstride < t1) ? 2 : 1;
+#pragma unroll 1
+      for (int u = 0; act && u < nsub; ++u) {
+        const float* zimg = lds + cur * 2 * kOp + u * (kOp / 2);
         const float* aimg = zimg + kOp;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
