@@ -809,6 +809,17 @@ class _ChainFn(torch.autograd.Function):
             elif k == "input_pt":
                 idx = st.t["x"]
                 if needs_grad[idx]:
+                    # Gradient fan-in: the same tensor enters this chain again further down as a layer's addend
+                    # (targets: attention query here, decoder input there).  Its other gradient is that layer's dZ,
+                    # stored by this very launch (same wave, same addresses): add it here and return one buffer,
+                    # instead of leaving autograd a separate pass over two point-sized tensors.
+                    for j2, gj in enumerate(grads):
+                        if (j2 != idx and isinstance(gj, tuple) and gj[1] == a["mod"] and gj[0].dtype == torch.float32
+                                and T[j2].data_ptr() == T[idx].data_ptr() and T[j2].shape == T[idx].shape
+                                and tuple(gj[0].shape) == pt_shape(chain.n_tasks, chain.pts, a["F"])
+                                and not any(g2 is gj for j3, g2 in enumerate(grads) if j3 != j2)):
+                            prog.add_pt(gj[0], a["F"])
+                            grads[j2] = None
                     buf = new_pt(a["F"])
                     prog.store_pt(buf, a["F"])
                     grads[idx] = (buf, a["mod"])
