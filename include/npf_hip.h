@@ -21,6 +21,7 @@
  *   npf_pack_pt/unpack_pt  layout change at the module boundary (no reference counterpart)
  *   npf_transpose        W -> W^T for the dgrad chains (no reference counterpart)
  *   npf_cast_bf16_weights  bf16 weight images for the bf16 compute mode (no reference counterpart)
+ *   npf_prepare_weights    the two above, batched over the layers of a chain (no reference counterpart)
  *   npf_gather_points    CntxtTrgtGetter.select              npf/utils/datasplit.py:246-255
  *   npf_split_heads/npf_merge_heads  MultiheadAttender._make_multiheaded / _concatenate_multiheads
  *                                                         npf/architectures/attention.py:505-527
@@ -228,6 +229,17 @@ int npf_gather_points(const float *x, const float *y, const int64_t *idx, int32_
  * transposed != 0: the image of src^T (rows = columns of src), for the dgrad chains. */
 int npf_cast_bf16_weights(const float *src, int32_t n_rows, int32_t n_cols, int32_t ld, int32_t transposed, void *dst,
                           void *stream);
+
+/* Batched weight preparation: up to NPF_MAX_WPREP_JOBS of the two functions above in ONE launch (a chain's
+ * dgrad needs W^T -- or, in the bf16 mode, an image -- of every layer; one 5 us launch per layer otherwise).
+ * kind: 0 = fp32 transpose (as npf_transpose, src row stride ld), 1 = bf16 image, 2 = bf16 image of src^T. */
+typedef struct npf_wprep_job {
+  const float *src; /* row-major [n_rows][n_cols], row stride ld floats */
+  void *dst;        /* kind 0: float [n_cols][n_rows]; kind 1 / 2: bf16 image, 16-byte aligned */
+  int32_t n_rows, n_cols, ld, kind;
+} npf_wprep_job_t;
+#define NPF_MAX_WPREP_JOBS 32
+int npf_prepare_weights(const npf_wprep_job_t *jobs, int32_t n_jobs, void *stream);
 
 /* Library / device info. */
 int npf_version(void);

@@ -51,7 +51,15 @@ class NpfWgradJob(C.Structure):
 
 
 NPF_MAX_WGRAD_JOBS = 16
-assert C.sizeof(NpfOp) == 72 and C.sizeof(NpfProgram) == 32 + 72 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 56
+
+
+class NpfWprepJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n_rows", C.c_int32), ("n_cols", C.c_int32), ("ld", C.c_int32),
+                ("kind", C.c_int32)]
+
+
+NPF_MAX_WPREP_JOBS = 32
+assert C.sizeof(NpfOp) == 72 and C.sizeof(NpfProgram) == 32 + 72 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 56 and C.sizeof(NpfWprepJob) == 32
 
 # name -> (restype, argtypes); must list every symbol declared in include/npf_hip.h
 _i32, _i64, _p = C.c_int32, C.c_int64, C.c_void_p
@@ -67,6 +75,7 @@ SIGNATURES = {
     "npf_unpack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "npf_transpose": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "npf_cast_bf16_weights": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "npf_prepare_weights": (C.c_int, [C.POINTER(NpfWprepJob), _i32, _p]),
     "npf_gather_points": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "npf_split_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_merge_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),

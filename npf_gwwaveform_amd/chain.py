@@ -15,7 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -343,6 +343,30 @@ def cast_bf16_weights(W: torch.Tensor, transposed: bool = False) -> torch.Tensor
     return out
 
 
+def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]]) -> List[torch.Tensor]:
+    """``npf_prepare_weights``: for every (W [N, K] row-major with unit column stride, kind) one output, all in one
+    launch per 32 matrices -- kind 0: W^T (fp32 [K, N]); 1: the bf16 image of W; 2: the bf16 image of W^T."""
+    outs: List[torch.Tensor] = []
+    lib = L.load()
+    for i0 in range(0, len(specs), L.NPF_MAX_WPREP_JOBS):
+        chunk = specs[i0:i0 + L.NPF_MAX_WPREP_JOBS]
+        arr = (L.NpfWprepJob * len(chunk))()
+        for j, (W, kind) in enumerate(chunk):
+            N, K = W.shape
+            if W.stride(1) != 1 or W.dtype != torch.float32:
+                raise ValueError("weight rows must be contiguous fp32")
+            if kind == 0:
+                out = torch.empty((K, N), dtype=torch.float32, device=W.device)
+            else:
+                rows, cols = (K, N) if kind == 2 else (N, K)
+                out = torch.empty((rows, pad32(cols)), dtype=torch.bfloat16, device=W.device)
+            arr[j].src, arr[j].dst = L.ptr(W, strided=True), out.data_ptr()
+            arr[j].n_rows, arr[j].n_cols, arr[j].ld, arr[j].kind = N, K, W.stride(0), kind
+            outs.append(out)
+        L.check(lib.npf_prepare_weights(arr, len(chunk), L.stream_ptr()), "npf_prepare_weights")
+    return outs
+
+
 def transpose(W: torch.Tensor) -> torch.Tensor:
     """W^T of a row-major [rows, cols] device matrix (npf_transpose)."""
     rows, cols = W.shape
@@ -553,6 +577,10 @@ class _ChainFn(torch.autograd.Function):
                 prog.store_pt(backed, F)
             return backed
 
+        images = {}  # bf16 mode: the weight images of all LINEAR steps, one launch
+        if bf16:
+            lin = [st.t["W"] for st in chain.steps if st.kind == "linear"]
+            images = dict(zip(lin, prepare_weights([(T[w], 1) for w in lin])))
         for i, st in enumerate(chain.steps):
             upstream_before.append(upstream)
             k, a = st.kind, st.a
@@ -578,7 +606,7 @@ class _ChainFn(torch.autograd.Function):
                 if a.get("add_rm") and train and (upstream or needs_grad[W] or needs_grad[add]):
                     raise NotImplementedError("row-major addends carry no gradient (inference path)")
                 if bf16:
-                    prog.linear_bf16(_bf16_image(T[W], False), a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
+                    prog.linear_bf16(images[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
                                      addend=T[add] if add >= 0 else None, addend_modulus=a["mod"],
                                      b_task_stride=(T[b].stride(0) if a["bpt"] else 0))
                 else:
@@ -700,6 +728,9 @@ class _ChainFn(torch.autograd.Function):
 
         n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows", "store_tr", "store_wb", "store_trb"))
         assert len(gouts) == n_out
+        # W^T (bf16 mode: the transposed image) of every layer the dgrad passes through, one launch
+        lin = [st.t["W"] for i, st in enumerate(chain.steps) if st.kind == "linear" and upstream_before[i]]
+        w_t = dict(zip(lin, prepare_weights([(T[w], 2 if ctx.bf16 else 0) for w in lin]))) if lin else {}
         for i in range(len(chain.steps) - 1, -1, -1):
             st = chain.steps[i]
             k, a = st.kind, st.a
@@ -743,10 +774,9 @@ class _ChainFn(torch.autograd.Function):
                         grads[add] = (dz, a["mod"])  # resolved after the launch
                 if upstream_before[i]:
                     if ctx.bf16:
-                        prog.linear_bf16(_bf16_image(T[W], True), a["N"], a["K"])
+                        prog.linear_bf16(w_t[W], a["N"], a["K"])
                     else:
-                        Wt = transpose(T[W])  # [K, N]
-                        prog.linear(Wt, a["N"], a["K"])
+                        prog.linear(w_t[W], a["N"], a["K"])  # W^T [K, N]
                 else:
                     started = False  # nothing upstream needs this gradient
                     break

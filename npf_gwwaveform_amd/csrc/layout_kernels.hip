@@ -140,6 +140,46 @@ __global__ void transpose_kernel(const float* __restrict__ src, int rows, int co
     if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+// Batched weight preparation (npf_prepare_weights): blockIdx.y = job, the blocks of a job stride over its work.
+struct WprepJobs {
+  npf_wprep_job_t job[NPF_MAX_WPREP_JOBS];
+};
+__global__ void prepare_weights_kernel(const WprepJobs J) {
+  __shared__ float tile[32][33];
+  const npf_wprep_job_t& jb = J.job[blockIdx.y];
+  const float* __restrict__ src = jb.src;
+  if (jb.kind == 0) {
+    float* __restrict__ dst = (float*)jb.dst;
+    const int rows = jb.n_rows, cols = jb.n_cols, ld = jb.ld;
+    const int tc = (cols + 31) / 32, tr = (rows + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tl = blockIdx.x; tl < tc * tr; tl += gridDim.x) {
+      const int c0 = (tl % tc) * 32, r0 = (tl / tc) * 32;
+      for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(size_t)(r0 + i) * ld + c0 + tx];
+      __syncthreads();
+      for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+      __syncthreads();
+    }
+  } else {
+    unsigned short* __restrict__ dst = (unsigned short*)jb.dst;
+    const bool transposed = jb.kind == 2;
+    const int rows = transposed ? jb.n_cols : jb.n_rows, cols = transposed ? jb.n_rows : jb.n_cols, ld = jb.ld;
+    const int Kp = ((cols + 31) >> 5) * 32;
+    const size_t total = (size_t)rows * Kp;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+      const int r = idx / Kp, q = idx - (size_t)r * Kp;
+      const int sgrp = q >> 5, g = (q & 31) >> 3, i = q & 7;
+      const int c = 32 * sgrp + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
+      float v = 0.f;
+      if (c < cols) v = transposed ? src[(size_t)c * ld + r] : src[(size_t)r * ld + c];
+      const __bf16 b = (__bf16)v;
+      dst[idx] = __builtin_bit_cast(unsigned short, b);
+    }
+  }
+}
+
 // out[task][f] = mean over valid points.  grid = (ceil(F/32), n_tasks); 256 threads = 8 feature quads x 32 points.
 __global__ void mean_agg_fwd_kernel(const float* __restrict__ R, int pts, int F, float* __restrict__ out) {
   const int tiles = (pts + 31) / 32;
@@ -252,6 +292,26 @@ extern "C" int npf_cast_bf16_weights(const float* src, int32_t n_rows, int32_t n
   const size_t total = (size_t)rows * npf::round_up(cols, 32);
   hipLaunchKernelGGL(npf::cast_bf16_weights_kernel, dim3(npf::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
                      n_rows, n_cols, ld, transposed, (unsigned short*)dst);
+  NPF_CHECK_LAUNCH();
+  return NPF_OK;
+}
+
+extern "C" int npf_prepare_weights(const npf_wprep_job_t* jobs, int32_t n_jobs, void* stream) {
+  if (!jobs || n_jobs <= 0 || n_jobs > NPF_MAX_WPREP_JOBS) return NPF_EINVAL;
+  npf::WprepJobs J;
+  size_t most = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const npf_wprep_job_t& b = jobs[j];
+    if (!b.src || !b.dst || b.n_rows <= 0 || b.n_cols <= 0 || b.ld < b.n_cols || b.kind < 0 || b.kind > 2) return NPF_EINVAL;
+    if (b.kind != 0 && (((uintptr_t)b.dst) & 15)) return NPF_EINVAL;
+    J.job[j] = b;
+    const size_t blocks = b.kind == 0 ? (size_t)((b.n_rows + 31) / 32) * ((b.n_cols + 31) / 32)
+                                      : ((size_t)b.n_rows * b.n_cols + 255) / 256;
+    most = blocks > most ? blocks : most;
+  }
+  for (int j = n_jobs; j < NPF_MAX_WPREP_JOBS; ++j) J.job[j] = jobs[0];
+  const unsigned gx = (unsigned)(most < 64 ? most : 64);
+  hipLaunchKernelGGL(npf::prepare_weights_kernel, dim3(gx ? gx : 1, n_jobs), dim3(256), 0, (hipStream_t)stream, J);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

@@ -311,6 +311,25 @@ def test_bf16_weight_image_layout():
         assert torch.equal(img, ref[:, src])
 
 
+def test_batched_weight_preparation_equals_the_single_launches():
+    """npf_prepare_weights (W^T, bf16 image, bf16 image of W^T for many matrices in one launch) is bit-identical to
+    npf_transpose / npf_cast_bf16_weights on each; strided rows, odd shapes, more than 32 jobs."""
+    CH, _ = _mods()
+    g = torch.Generator().manual_seed(61)
+    specs, refs = [], []
+    for n, (N, K) in enumerate([(256, 256), (37, 70), (4, 256), (256, 3), (128, 96), (1, 1)] * 7):
+        big = torch.randn(N, K + 5, generator=g).to(DEV)
+        W = big[:, :K] if n % 2 else big[:, :K].contiguous()      # (row stride K + 5 or K)
+        kind = n % 3
+        specs.append((W, kind))
+        refs.append(CH.transpose(W.contiguous()) if kind == 0 else CH.cast_bf16_weights(W, transposed=kind == 2))
+    outs = CH.prepare_weights(specs)
+    assert len(outs) == len(refs) == 42
+    for (W, kind), o, r in zip(specs, outs, refs):
+        assert o.dtype == r.dtype and o.shape == r.shape
+        assert torch.equal(o.view(torch.int16) if kind else o, r.view(torch.int16) if kind else r), (tuple(W.shape), kind)
+
+
 def test_bf16_wgrad_matches_bf16_emulation():
     """wgrad kernel in the bf16 compute mode (NPF_WGRAD_BF16, v_mfma_f32_16x16x16_bf16): dW and db equal the
     contraction of the bf16-rounded operands (fp32 accumulation; db sums the unrounded dZ)."""
