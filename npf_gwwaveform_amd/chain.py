@@ -348,6 +348,8 @@ def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]]) -> List[torch.Ten
     launch per 32 matrices -- kind 0: W^T (fp32 [K, N]); 1: the bf16 image of W; 2: the bf16 image of W^T."""
     outs: List[torch.Tensor] = []
     lib = L.load()
+    if os.environ.get("NPF_NO_BATCH_PREP") == "1":  # debug switch: one launch per matrix
+        return [transpose(W.contiguous()) if kind == 0 else cast_bf16_weights(W, transposed=kind == 2) for W, kind in specs]
     for i0 in range(0, len(specs), L.NPF_MAX_WPREP_JOBS):
         chunk = specs[i0:i0 + L.NPF_MAX_WPREP_JOBS]
         arr = (L.NpfWprepJob * len(chunk))()
