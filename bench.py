@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
-"""Benchmark of the neural-process train step on MI355X (see DESIGN.md section "Measurement").
+"""Benchmark of the neural-process hot path on MI355X (see DESIGN.md section "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
-A step = forward + loss + backward + (N > 1: bucketed RCCL gradient all-reduce) + Adam on one
-synthetic batch of the BASELINE.json config-2 workload: AttnCNP (scaledot), r = 256, 4-layer
-xy-encoder / decoder, 256 context and 1024 target frequency points, 256 tasks PER GPU, fp32
-(weak scaling).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line.  For N > 1 launch with ``python -m torch.distributed.run --nproc-per-node N``.
+Default (= ``--config c2``): a step = forward + loss + backward + (N > 1: bucketed RCCL gradient
+all-reduce) + Adam on one synthetic batch of the BASELINE.json config-2 workload: AttnCNP
+(scaledot), r = 256, 4-layer xy-encoder / decoder, 256 context and 1024 target frequency points,
+256 tasks PER GPU, fp32 (weak scaling).  ``c3`` = the same model with bf16 products, 1024 tasks per
+GPU; ``c4`` = the data-parallel configuration, 1024 tasks per GPU (8192 global at N = 8), fp32 or
+``--dtype bf16``; ``c5`` = decode only (r = 512 decoder, 4096 targets, 512 waveforms per GPU).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+N > 1: either launch the ranks yourself (``python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...``) or call ``python bench.py --gpus N`` bare: the process then starts N ranks
+as children (before it has touched the GPU) and exits with their status.  A world size that differs
+from ``--gpus`` is an error, never a silent downgrade.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 import warnings
@@ -22,15 +32,214 @@ from functools import partial
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_16x16x4_f32) = vector peak
-PEAK_HBM_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_16x16x4_f32) = vector peak
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
+PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FLOP_PER_PT_TRAIN = {"attncnp": 4_148_544, "attnlnp": 6_952_768}  # SURVEY.md 8d (FlopCounterMode on the reference)
+FLOP_PER_PT_DECODE_R512_L4 = 3_149_824  # (L+2) 2 r^2 + 4 r dy at r = 512, L = 4, dy = 2
+
+# --config presets: workload, dtype, tasks per GPU, target points, width, BASELINE.json config number
+CONFIGS = {
+    "c2": dict(workload="train", dtype="fp32", batch=256, trgt=1024, r=256, number=2),
+    "c3": dict(workload="train", dtype="bf16", batch=1024, trgt=1024, r=256, number=3),
+    "c4": dict(workload="train", dtype="fp32", batch=1024, trgt=1024, r=256, number=4),
+    "c5": dict(workload="decode", dtype="fp32", batch=512, trgt=4096, r=512, number=5),
+}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (c2 = the headline metric and the default; c3 = bf16, 1024 tasks; "
+                         "c4 = data parallel, 1024 tasks per GPU, fp32 unless --dtype bf16; c5 = decode only)")
+    ap.add_argument("--workload", default=None, choices=["train", "decode"], help="(older spelling) train = c2, decode = c5")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="attncnp", choices=["attncnp", "attnlnp"])
+    ap.add_argument("--batch", type=int, default=None, help="tasks per GPU (overrides the preset)")
+    ap.add_argument("--ctx", type=int, default=256)
+    ap.add_argument("--trgt", type=int, default=None, help="target points per task (overrides the preset)")
+    ap.add_argument("--r", type=int, default=None, help="feature width (overrides the preset)")
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16"],
+                    help="fp32 | bf16 (bf16 MFMA products in the MLP stacks, attention and weight gradients; fp32 accumulation)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the train step from a captured HIP graph (Trainer(use_graph=True); single rank only; "
+                         "skips the per-step host-side input range check) -- not the default measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args(argv)
+    if args.config is None:
+        if args.workload == "decode":
+            args.config = "c5"
+        else:
+            args.config = "c3" if args.dtype == "bf16" else "c2"
+    preset = CONFIGS[args.config]
+    if args.workload is not None and args.workload != preset["workload"]:
+        ap.error(f"--config {args.config} is a {preset['workload']} workload")
+    args.workload = preset["workload"]
+    args.dtype = preset["dtype"] if args.dtype is None else args.dtype
+    if args.workload == "decode" and args.dtype != "fp32":
+        ap.error("the decode-only workload is fp32")
+    if args.config in ("c2",) and args.dtype != "fp32":
+        ap.error("config c2 is fp32 (bf16 is c3)")
+    args.preset = (args.batch is None and args.trgt is None and args.r is None and args.ctx == 256 and args.layers == 4)
+    args.batch = preset["batch"] if args.batch is None else args.batch
+    args.trgt = preset["trgt"] if args.trgt is None else args.trgt
+    args.r = preset["r"] if args.r is None else args.r
+    args.config_number = preset["number"]
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+# ---------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as children BEFORE this process touches the GPU
+# ---------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` called bare: run ``torch.distributed.run`` with N ranks of this same
+    command as a child process and return its exit status.  Nothing here initialises HIP
+    (``device_count`` does not on this image), and no process that did is ever re-exec'ed."""
+    import torch
+
+    rehearsal = os.environ.get("NPF_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not rehearsal:
+        print(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# ---------------------------------------------------------------------------------------
+# host description + CPU baseline (the oracle, timed on the host cores; rank 0, N = 1 only)
+# ---------------------------------------------------------------------------------------
+def host_cpu():
+    """(model name, physical cores of the host, logical CPUs this process may run on)."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None and cid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except Exception:
+        allowed = os.cpu_count() or 1
+    return model, (len(phys) or (os.cpu_count() or 1)), allowed
+
+
+def _time_steps(step, budget_s: float, max_n: int = 200):
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= max_n:
+            return n, el
+
+
+def cpu_baseline(kind: str, r: int, L: int, C: int, T: int, budget_s: float = 10.0):
+    """The oracle (CPU restatement of the reference, oracle/npf_oracle.py) on the host cores: the same
+    train step (forward, loss, backward, Adam lr 1e-3) at the same shapes with batch 32, once
+    on every core this process may use (the box's CPU share; at most the host's physical cores) and once on
+    8 threads."""
+    import torch
+    from oracle import npf_oracle as O
+    from npf_gwwaveform_amd.train import synthetic_waveform_batch
+
+    model, phys, allowed = host_cpu()
+    cores = max(1, min(allowed, phys, int(os.environ.get("NPF_CPU_BASELINE_THREADS", "1024"))))
+    B = 32
+    cfg = O.OracleConfig(kind="AttnCNP" if kind == "attncnp" else "AttnLNP", x_dim=1, y_dim=2, r_dim=r,
+                         is_q_zCct=(kind != "attncnp"))
+    params = {k: v.clone().requires_grad_(True) for k, v in O.init_params(cfg, 0, L, L).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    batch = synthetic_waveform_batch(B, C, T, 99, "cpu")
+    eps = torch.randn(1, B, 1, r) if kind != "attncnp" else None
+    loss_fn = O.cnpf_loss if kind == "attncnp" else O.elbo_loss
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = O.forward(cfg, params, batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"], eps=eps)
+        loss_fn(out, batch["Y_trgt"]).backward()
+        opt.step()
+
+    legs = {}
+    for n_thr in dict.fromkeys([cores, min(8, cores)]):
+        torch.set_num_threads(n_thr)
+        n, el = _time_steps(step, budget_s)
+        legs[n_thr] = (B * T * n / el, n, el)
+    v, n, el = legs[cores]
+    out = {"value": v, "unit": "target-points/s", "cores": cores, "kind": "port",
+           "cpu_model": model, "host_physical_cores": phys, "cpus_allowed": allowed,
+           "sample": f"{n} train steps (fwd+loss+bwd+Adam) of the CPU oracle at the same shapes with batch {B} "
+                     f"(C={C}, T={T}, r={r}, L={L}), {el:.1f} s, torch {torch.__version__} CPU, {cores} threads "
+                     f"= every core this process may use on {model} ({phys} physical cores on the host)"}
+    if min(8, cores) != cores:
+        v8, n8, el8 = legs[min(8, cores)]
+        out["value_8_threads"] = v8
+        out["sample_8_threads"] = f"{n8} steps, {el8:.1f} s, 8 threads"
+    return out
+
+
+def cpu_baseline_decode(r: int, L: int, T: int, budget_s: float = 10.0):
+    """The oracle's decode(X_trgt_enc, R_trgt) (base.py:327-367 restated) on the host cores, batch 2."""
+    import torch
+    from oracle import npf_oracle as O
+
+    model, phys, allowed = host_cpu()
+    cores = max(1, min(allowed, phys, int(os.environ.get("NPF_CPU_BASELINE_THREADS", "1024"))))
+    B = 2
+    cfg = O.OracleConfig(kind="CNP", x_dim=1, y_dim=2, r_dim=r)
+    params = O.init_params(cfg, 0, 2, L)
+    g = torch.Generator().manual_seed(5)
+    Xt, R = torch.randn(B, T, r, generator=g) * 0.5, torch.randn(1, B, T, r, generator=g) * 0.5
+    legs = {}
+    with torch.no_grad():
+        for n_thr in dict.fromkeys([cores, min(8, cores)]):
+            torch.set_num_threads(n_thr)
+            n, el = _time_steps(lambda: O.decode(cfg, params, Xt, R), budget_s)
+            legs[n_thr] = (B * T * n / el, n, el)
+    v, n, el = legs[cores]
+    out = {"value": v, "unit": "target-points/s", "cores": cores, "kind": "port",
+           "cpu_model": model, "host_physical_cores": phys, "cpus_allowed": allowed,
+           "sample": f"{n} decode passes of the CPU oracle with batch {B} (T={T}, r={r}, L={L}), {el:.1f} s, "
+                     f"torch {torch.__version__} CPU, {cores} threads on {model}"}
+    if min(8, cores) != cores:
+        out["value_8_threads"] = legs[min(8, cores)][0]
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# the measured workloads
+# ---------------------------------------------------------------------------------------
 def build_model(kind: str, r: int, L: int, device):
+    import torch
     import npf_gwwaveform_amd as A
 
     torch.manual_seed(0)
@@ -48,53 +257,8 @@ def build_model(kind: str, r: int, L: int, device):
     return m.to(device), crit
 
 
-def cpu_baseline(kind: str, r: int, L: int, C: int, T: int, budget_s: float = 12.0):
-    """The oracle (CPU restatement of the reference, oracle/npf_oracle.py) on the host cores:
-    the same train step (forward, loss, backward, Adam lr 1e-3) at the same shapes, on a
-    bounded sample (small batch, a few steps)."""
-    from oracle import npf_oracle as O
-    from npf_gwwaveform_amd.train import synthetic_waveform_batch
-
-    avail = os.cpu_count() or 1
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    # a 1-GPU box's CPU share is 16 cores (more threads than that oversubscribe the host)
-    cores = max(1, min(avail, int(os.environ.get("NPF_CPU_BASELINE_THREADS", "16"))))
-    torch.set_num_threads(cores)
-    B = 8
-    cfg = O.OracleConfig(kind="AttnCNP" if kind == "attncnp" else "AttnLNP", x_dim=1, y_dim=2, r_dim=r,
-                         is_q_zCct=(kind != "attncnp"))
-    params = {k: v.clone().requires_grad_(True) for k, v in O.init_params(cfg, 0, L, L).items()}
-    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
-    batch = synthetic_waveform_batch(B, C, T, 99, "cpu")
-    eps = torch.randn(1, B, 1, r) if kind != "attncnp" else None
-    loss_fn = O.cnpf_loss if kind == "attncnp" else O.elbo_loss
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = O.forward(cfg, params, batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"], eps=eps)
-        loss_fn(out, batch["Y_trgt"]).backward()
-        opt.step()
-
-    step()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
-            break
-    return {"value": B * T * n / el, "unit": "target-points/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps (fwd+loss+bwd+Adam) of the CPU oracle at the same shapes with batch {B} "
-                      f"(C={C}, T={T}, r={r}, L={L}), {el:.1f} s, torch {torch.__version__} CPU, {cores} threads"}
-
-
-FLOP_PER_PT_DECODE_R512_L4 = 3_149_824  # SURVEY.md 8a row 3 / 8d: (L+2) 2 r^2 + 4 r dy at r = 512, L = 4, dy = 2
-
-
 def decode_model(r: int, L: int, device):
+    import torch
     import npf_gwwaveform_amd as A
 
     torch.manual_seed(0)
@@ -104,93 +268,125 @@ def decode_model(r: int, L: int, device):
     return m.to(device).eval()
 
 
-def cpu_baseline_decode(r: int, L: int, T: int, budget_s: float = 12.0):
-    """The oracle's decode(X_trgt_enc, R_trgt) (base.py:327-367 restated) on the host cores, batch 2."""
-    from oracle import npf_oracle as O
+def timed_region(step, n_steps: int, sync):
+    """EXACTLY ``n_steps`` steps between two barrier + device-synchronize brackets (wall clock), plus one
+    HIP event per step boundary on the launch stream (no host sync inside the region) for the spread."""
+    import torch
 
-    avail = os.cpu_count() or 1
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = max(1, min(avail, int(os.environ.get("NPF_CPU_BASELINE_THREADS", "16"))))
-    torch.set_num_threads(cores)
-    B = 2
-    cfg = O.OracleConfig(kind="CNP", x_dim=1, y_dim=2, r_dim=r)
-    params = O.init_params(cfg, 0, 2, L)
-    g = torch.Generator().manual_seed(5)
-    Xt, R = torch.randn(B, T, r, generator=g) * 0.5, torch.randn(1, B, T, r, generator=g) * 0.5
-    with torch.no_grad():
-        O.decode(cfg, params, Xt, R)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            O.decode(cfg, params, Xt, R)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 200:
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+    sync()
+    t0 = time.perf_counter()
+    evs[0].record()
+    last = None
+    for i in range(n_steps):
+        last = step(i)
+        evs[i + 1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)]
+    spread = {"min": min(per), "median": statistics.median(per), "max": max(per), "source": "HIP events between steps"}
+    return elapsed, spread, last
+
+
+def profile_launches(step, n_prof: int, rank: int, sync, CH):
+    """Instrumented pass after the timed region: HIP events around every kernel launch on the launch
+    stream (rank 0); every rank runs the steps because a train step contains the gradient all-reduce."""
+    if rank == 0:
+        CH.PROFILE = []
+    for i in range(n_prof):
+        step(i)
+    sync()
+    if rank != 0:
+        return None, {}
+    prof, CH.PROFILE = CH.PROFILE, None
+    if os.environ.get("NPF_BENCH_VERBOSE"):
+        per = len(prof) // n_prof
+        for name, flops, e0, e1, nbytes in prof[-per:]:
+            ms = e0.elapsed_time(e1)
+            print(f"  {name:14s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s "
+                  f"{nbytes * 1e-9:7.3f} GB (algorithmic) {nbytes / ms * 1e-6:7.0f} GB/s", file=sys.stderr)
+    agg = {}
+    for name, flops, e0, e1, nbytes in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+        a[3] += nbytes
+    kernels = {}
+    for name, (n, fl, sec, nb) in agg.items():
+        kernels[name] = {"launches_per_step": n / n_prof, "avg_launch_ms": sec / n * 1e3,
+                         "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
+                         "algorithmic_hbm_gb_per_launch": nb / n * 1e-9, "algorithmic_hbm_gbps": nb / sec * 1e-9}
+    return agg, kernels
+
+
+def roofline_of(agg, dtype: str, tag: str, preset: bool):
+    """The dominant kernel (most device time) against its roofline.  fp32 launches are bound by the fp32
+    MFMA rate.  bf16 launches have 1/16 of those MFMA cycles and are priced against both rooflines; the line
+    carries the larger fraction (the binding one)."""
+    name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
+    tf, gbps = fl / sec * 1e-12, nb / sec * 1e-9
+    if dtype == "bf16":
+        f_m, f_h = tf / PEAK_BF16_TFLOPS, gbps / PEAK_HBM_GBPS
+        if f_h >= f_m:
+            roof = {"kernel": name, "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": f_h}
+        else:
+            roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": f_m}
+        roof["frac_mfma_bf16"], roof["frac_hbm"] = f_m, f_h
+        roof["achieved_tflops_algorithmic"], roof["achieved_gbps_algorithmic"] = tf, gbps
+    else:
+        roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / PEAK_F32_TFLOPS, "achieved_gbps_algorithmic": gbps}
+    roof["traffic"] = None
+    # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    # rocprofv3 --pmc passes of this same command), condensed by tools/summarize_profiles.py into
+    # profiles/<round>_<config>_summary.json -- only quoted when this run has the shapes those passes had
+    if preset:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_summary.json")), reverse=True):
+            try:
+                k = json.load(open(f))["kernels"].get("npf::" + name)
+            except Exception:
+                continue
+            if k and "hbm_bytes_per_launch" in k:
+                roof["traffic"] = k["hbm_bytes_per_launch"]
+                roof["traffic_unit"] = "bytes/launch"
+                roof["traffic_source"] = os.path.relpath(f, ROOT)
                 break
-    return {"value": B * T * n / el, "unit": "target-points/s", "cores": cores, "kind": "port",
-            "sample": f"{n} decode passes of the CPU oracle with batch {B} (T={T}, r={r}, L={L}), {el:.1f} s, "
-                      f"torch {torch.__version__} CPU, {cores} threads"}
+    return roof
 
 
-def main_decode(args, rank, world, dev):
+def main_decode(args, rank, world, dev, sync):
     """BASELINE config 5 per GPU: decode(X_trgt_enc, R_trgt) only, 512-wide 4-layer decoder, 4096
     target points per waveform, 4096 / 8 = 512 waveforms per GPU, encoder outputs resident in HBM."""
+    import torch
+    import torch.distributed as dist
     from npf_gwwaveform_amd import chain as CH
 
-    r, L, T = args.r, args.layers, args.trgt
-    B = args.batch
+    r, L, T, B = args.r, args.layers, args.trgt, args.batch
     model = decode_model(r, L, dev)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     Xt = torch.randn(B, T, r, device=dev, generator=g) * 0.5
     R = torch.randn(1, B, T, r, device=dev, generator=g) * 0.5
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def step():
+    def step(_i=0):
         with torch.no_grad():
             p = model.decode(Xt, R)
         return p.base_dist.loc
 
     for _ in range(args.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loc = step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, spread, loc = timed_region(step, args.steps, sync)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * B * T * args.steps / elapsed
     roofline, kernels = None, {}
-    if rank == 0 and not args.no_roofline:
-        CH.PROFILE = []
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        agg = {}
-        for name, flops, e0, e1, nbytes in CH.PROFILE:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
-            a[3] += nbytes
-        CH.PROFILE = None
-        for name, (n, fl, sec, nb) in agg.items():
-            kernels[name] = {"launches_per_step": n / 2, "avg_launch_ms": sec / n * 1e3,
-                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
-                             "algorithmic_hbm_gb_per_launch": nb / n * 1e-9}
-        name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
-        ach = fl / sec * 1e-12
-        roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
+    if not args.no_roofline:
+        agg, kernels = profile_launches(step, 2, rank, sync, CH)
+        if rank == 0:
+            roofline = roofline_of(agg, "fp32", "c5", args.preset)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_decode(r, L, T)
@@ -199,6 +395,7 @@ def main_decode(args, rank, world, dev):
         print(json.dumps({
             "metric": "waveform target-points/sec (decode only)", "value": value, "unit": "target-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_spread": spread,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config 5: decode(X_trgt_enc, R_trgt) only, {r}-wide {L}-layer decoder, {T} target "
                                    f"points per waveform, {B} waveforms per GPU, fp32, encoder outputs resident in HBM "
@@ -209,38 +406,95 @@ def main_decode(args, rank, world, dev):
             "roofline": roofline, "cpu_baseline": cpu}))
 
 
+def main_train(args, rank, world, dev, sync, rehearsal):
+    import torch
+    import torch.distributed as dist
+    from npf_gwwaveform_amd import chain as CH
+    from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
+
+    B, C, T = args.batch, args.ctx, args.trgt
+    if args.dtype == "bf16":
+        import npf_gwwaveform_amd as A
+
+        A.set_compute_dtype("bf16")
+    model, crit = build_model(args.model, args.r, args.layers, dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    trainer = Trainer(model, crit, lr=1e-3, world=world, use_graph=args.graph)
+    batches = [synthetic_waveform_batch(B, C, T, 1234 + rank * 10**6 + i, dev) for i in range(4)]
+
+    def step(i):
+        return trainer.step(batches[i % len(batches)])
+
+    for i in range(args.warmup):
+        step(i)
+    elapsed, spread, loss = timed_region(step, args.steps, sync)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * T * args.steps / elapsed
+    loss_val = float(loss.item())
+
+    roofline, kernels = None, {}
+    if args.graph:
+        args.no_roofline = True  # (HIP events per launch cannot be recorded inside a graph replay)
+    if not args.no_roofline:
+        agg, kernels = profile_launches(step, 3, rank, sync, CH)
+        if rank == 0:
+            tag = args.config if not (args.config == "c4" and args.dtype == "bf16") else "c4bf16"
+            roofline = roofline_of(agg, args.dtype, tag, args.preset and args.model == "attncnp")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.r, args.layers, C, T)
+
+    if rank == 0:
+        flop_pt = FLOP_PER_PT_TRAIN[args.model] if (args.r, args.layers, C, T) == (256, 4, 256, 1024) else None
+        model_name = "AttnCNP" if args.model == "attncnp" else "AttnLNP(is_q_zCct, n_z=1)"
+        line = {
+            "metric": "waveform target-points/sec (train step)",
+            "value": value,
+            "unit": "target-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_spread": spread,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
+            "config": {
+                "workload": f"BASELINE config {args.config_number}: {model_name} scaledot, r={args.r}, {args.layers}-layer "
+                            f"xy-encoder/decoder, {C} context / {T} target points, {B} tasks per GPU ({B * world} global), "
+                            f"{args.dtype} train step (fwd+loss+bwd+allreduce+Adam)",
+                "name": args.config, "tasks_per_gpu": B, "global_tasks": B * world, "context_points": C, "target_points": T,
+                "r_dim": args.r, "n_params": n_params, "parallelism": f"dp{world}", "final_loss": loss_val,
+                "hip_graph": bool(args.graph),
+                "train_step_tflops_algorithmic": (value * flop_pt * 1e-12) if flop_pt else None,
+                "kernels": kernels,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="train", choices=["train", "decode"],
-                    help="train = BASELINE config 2 (the headline metric); decode = config 5 (decode-only, r=512, T=4096)")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="attncnp", choices=["attncnp", "attnlnp"])
-    ap.add_argument("--batch", type=int, default=None, help="tasks per GPU (train: 256, decode: 512)")
-    ap.add_argument("--ctx", type=int, default=256)
-    ap.add_argument("--trgt", type=int, default=None, help="target points per task (train: 1024, decode: 4096)")
-    ap.add_argument("--r", type=int, default=None, help="feature width (train: 256, decode: 512)")
-    ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = BASELINE config 2 (headline); bf16 = config 3's compute mode (bf16 MFMA in the MLP stacks, "
-                         "fp32 attention / accumulation / weight gradients), 1024 tasks per GPU by default")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the train step from a captured HIP graph (Trainer(use_graph=True); single rank only; "
-                         "skips the per-step host-side input range check) -- not the default measurement")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-    dflt = {"train": (1024 if args.dtype == "bf16" else 256, 1024, 256), "decode": (512, 4096, 512)}[args.workload]
-    args.batch = dflt[0] if args.batch is None else args.batch
-    args.trgt = dflt[1] if args.trgt is None else args.trgt
-    args.r = dflt[2] if args.r is None else args.r
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined (WORLD_SIZE={world_env})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # rehearsal on a one-GPU box (not a measurement): NPF_BENCH_REHEARSAL=1 puts every rank on
@@ -256,142 +510,22 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-
-    if args.workload == "decode":
-        main_decode(args, rank, world, dev)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    from npf_gwwaveform_amd import chain as CH
-    from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
-
-    B, C, T = args.batch, args.ctx, args.trgt
-    if args.dtype == "bf16":
-        import npf_gwwaveform_amd as A
-
-        A.set_compute_dtype("bf16")
-    model, crit = build_model(args.model, args.r, args.layers, dev)
-    n_params = sum(p.numel() for p in model.parameters())
-    trainer = Trainer(model, crit, lr=1e-3, world=world, use_graph=args.graph)
-    batches = [synthetic_waveform_batch(B, C, T, 1234 + rank * 10**6 + i, dev) for i in range(4)]
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        trainer.step(batches[i % len(batches)])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = trainer.step(batches[i % len(batches)])
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = world * B * T * args.steps / elapsed
-    loss_val = float(loss.item())
-
-    roofline = None
-    kernels = {}
-    n_prof = 3
-    if args.graph:
-        args.no_roofline = True  # (HIP events per launch cannot be recorded inside a graph replay)
-    if not args.no_roofline:
-        # instrumented pass: HIP events around every kernel launch on the launch stream (rank 0);
-        # every rank runs these steps because a step contains the gradient all-reduce
-        if rank == 0:
-            CH.PROFILE = []
-        for i in range(n_prof):
-            trainer.step(batches[i % len(batches)])
-        sync()
-    if rank == 0 and not args.no_roofline:
-        agg = {}
-        if os.environ.get("NPF_BENCH_VERBOSE"):
-            per = len(CH.PROFILE) // n_prof
-            for name, flops, e0, e1, nbytes in CH.PROFILE[-per:]:
-                ms = e0.elapsed_time(e1)
-                print(f"  {name:14s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s "
-                      f"{nbytes * 1e-9:7.3f} GB (algorithmic) {nbytes / ms * 1e-6:7.0f} GB/s", file=sys.stderr)
-        for name, flops, e0, e1, nbytes in CH.PROFILE:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
-            a[3] += nbytes
-        CH.PROFILE = None
-        for name, (n, fl, sec, nb) in agg.items():
-            kernels[name] = {"launches_per_step": n / n_prof, "avg_launch_ms": sec / n * 1e3,
-                             "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
-                             "algorithmic_hbm_gb_per_launch": nb / n * 1e-9}
-        dom = max(agg.items(), key=lambda kv: kv[1][2])
-        name, (n, fl, sec, nb) = dom
-        ach = fl / sec * 1e-12
-        roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
-        if args.dtype == "bf16" and name == "chain_kernel":
-            # bf16 MLP layers have 1/16 of the MFMA cycles of their fp32 form: these launches are priced
-            # against HBM by their algorithmic bytes (PT16 tensors counted at 2 bytes per value)
-            gbps = nb / sec * 1e-9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": gbps / PEAK_HBM_GBPS, "traffic": None, "achieved_tflops_algorithmic": ach}
-        # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-        # separate rocprofv3 --pmc passes of this same command), condensed by
-        # tools/summarize_profiles.py into profiles/<round>_summary.json
-        import glob
-        profiled = {"fp32": (256, 256, 1024, 256), "bf16": (1024, 256, 1024, 256)}[args.dtype]  # the shapes the PMC passes ran
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
-            if ("bf16" in os.path.basename(f)) != (args.dtype == "bf16"):
-                continue
-            try:
-                k = json.load(open(f))["kernels"].get("npf::" + name)
-                if k and "hbm_bytes_per_launch" in k and (B, C, T, args.r) == profiled and args.workload == "train":
-                    roofline["traffic"] = k["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes/launch"
-                    roofline["traffic_source"] = os.path.relpath(f, ROOT)
-                    break
-            except Exception:
-                pass
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.model, args.r, args.layers, C, T)
-
-    if rank == 0:
-        flop_pt = FLOP_PER_PT_TRAIN[args.model] if (args.r, args.layers, C, T) == (256, 4, 256, 1024) else None
-        line = {
-            "metric": "waveform target-points/sec (train step)",
-            "value": value,
-            "unit": "target-points/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
-            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
-            "config": {
-                "workload": f"BASELINE config {2 if args.dtype == 'fp32' else 3}: {'AttnCNP' if args.model == 'attncnp' else 'AttnLNP(is_q_zCct, n_z=1)'} "
-                            f"scaledot, r={args.r}, {args.layers}-layer xy-encoder/decoder, {C} context / {T} target "
-                            f"points, {B} tasks per GPU, {args.dtype} train step (fwd+loss+bwd+allreduce+Adam)",
-                "tasks_per_gpu": B, "global_tasks": B * world, "context_points": C, "target_points": T,
-                "r_dim": args.r, "n_params": n_params, "parallelism": f"dp{world}", "final_loss": loss_val,
-                "hip_graph": bool(args.graph),
-                "train_step_tflops_algorithmic": (value * flop_pt * 1e-12) if flop_pt else None,
-                "kernels": kernels,
-            },
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    try:
+        if args.workload == "decode":
+            main_decode(args, rank, world, dev, sync)
+        else:
+            main_train(args, rank, world, dev, sync, rehearsal)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

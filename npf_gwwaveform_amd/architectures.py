@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import functional as FN
 from ._lib import NPF_MAX_TRAIN_FEATURES
-from .chain import Chain
+from .chain import Chain, PTensor
 
 __all__ = ["MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender",
            "SelfAttention", "get_attender"]
@@ -154,25 +154,12 @@ class MergeFlatInputs(nn.Module):
             raise NotImplementedError("a SelfAttention flat module is not one chain: use run_pt")
         return self.flat_module.append_to(ch)
 
-    def run_pt(self, ch: Chain, x1_pt, n_tasks: int, pts: int, with_tr: bool = False, **kw):
-        """Finish ``ch`` (cur = x2) with this module and run it: PT32 output [n_tasks, pts, n_out]
-        (with ``_npf_tr`` set to the feature-major copy when ``with_tr``).  One launch for an MLP flat
+    def run_pt(self, ch: Chain, x1_pt, n_tasks: int, pts: int, with_tr: bool = False, **kw) -> PTensor:
+        """Finish ``ch`` (cur = x2) with this module and run it: a :class:`PTensor` [n_tasks, pts, n_out]
+        (carrying the feature-major copy / bf16 images when ``with_tr``).  One launch for an MLP flat
         module; for a SelfAttention flat module the merge is a launch and the attention layers follow."""
         if isinstance(self.flat_module, MLP):
-            from . import chain as _chain
-
-            self.append_to(ch, x1_pt=x1_pt, **kw).output_pt()
-            imgs = with_tr and _chain.COMPUTE_DTYPE == "bf16"
-            if with_tr:
-                ch.store_tr()
-            if imgs:
-                ch.store_bf16_images()
-            outs = ch.run()
-            if with_tr:
-                outs[0]._npf_tr = outs[1]
-            if imgs:
-                outs[0]._npf_img = (outs[2], outs[3])
-            return outs[0]
+            return self.append_to(ch, x1_pt=x1_pt, **kw).run_pt(as_weights=with_tr)
         rl = self.resizer.layers()
         for lin in rl[:-1]:
             ch.linear(lin.weight, lin.bias, relu=True)
@@ -197,7 +184,7 @@ class MergeFlatInputs(nn.Module):
             ch = Chain(n2, T, x1.device)
             ch.input_pt(FN.pack_pt(x2.reshape(n2, T, x2.shape[-1])), x2.shape[-1])
             y = self.run_pt(ch, FN.pack_pt(x1.reshape(n1, T, d1)), n2, T, x1_modulus=(n1 if n1 != n2 else 0))
-            return FN.unpack_pt(y, T, n_out).reshape(*lead2, T, n_out)
+            return FN.unpack_pt(y.t, T, n_out).reshape(*lead2, T, n_out)
         ch = Chain(n2, T, x1.device)
         d2 = x2.shape[-1]
         no_grad = not torch.is_grad_enabled() or not (x1.requires_grad or x2.requires_grad or
@@ -414,7 +401,7 @@ class SelfAttention(nn.Module):
     def reset_parameters(self):  # weights_init is a no-op
         pass
 
-    def forward_pt(self, x_pt, n_tasks: int, pts: int, with_tr: bool = False):
+    def forward_pt(self, x_pt, n_tasks: int, pts: int, with_tr: bool = False) -> PTensor:
         out = x_pt
         for layer in self.attn_layers:
             out = layer.attend_pt(out, out, out, pts, pts)
@@ -423,14 +410,8 @@ class SelfAttention(nn.Module):
             ch.input_pt(out, self.x_dim)
             if self.is_resize:
                 ch.linear(self.resize.weight, self.resize.bias)
-            ch.output_pt()
-            if with_tr:
-                ch.store_tr()
-            outs = ch.run()
-            out = outs[0]
-            if with_tr:
-                out._npf_tr = outs[1]
-        return out
+            return ch.run_pt(as_weights=with_tr)
+        return PTensor(out, pts, self.x_dim)
 
     def forward(self, X, positions=None):
         if positions is not None:
@@ -438,7 +419,7 @@ class SelfAttention(nn.Module):
         lead, P, d = X.shape[:-2], X.shape[-2], X.shape[-1]
         n = int(math.prod(lead)) if len(lead) else 1
         out = self.forward_pt(FN.pack_pt(X.reshape(n, P, d)), n, P)
-        return FN.unpack_pt(out, P, self.out_dim).reshape(*lead, P, self.out_dim)
+        return FN.unpack_pt(out.t, P, self.out_dim).reshape(*lead, P, self.out_dim)
 
 
 def get_attender(attention, kq_size, value_size, out_size, **kwargs):

@@ -94,6 +94,28 @@ def pt_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
     return torch.empty(pt_shape(n_tasks, pts, F), dtype=torch.float32, device=device)
 
 
+@dataclass
+class PTensor:
+    """A per-point activation between chains: the PT32 tensor together with everything a later stage has to
+    know about it.  The geometry travels with the data (a PT32 tensor's own shape only gives the padded
+    sizes), and so do the companion copies an attention chain streams as per-task weights."""
+    t: torch.Tensor                       # PT32 [n_tasks, tiles, pad32(F)/4, 32, 4] fp32 (carries the autograd graph)
+    pts: int                              # valid points per task
+    F: int                                # valid features
+    tr: Optional[torch.Tensor] = None     # feature-major copy [n_tasks, F, 32*tiles] (``Chain.store_tr``)
+    img: Optional[Tuple[torch.Tensor, torch.Tensor]] = None  # bf16 row / transposed images (bf16 compute mode)
+
+    def __post_init__(self):
+        want = pt_shape(self.t.shape[0], self.pts, self.F)
+        if tuple(self.t.shape) != want:
+            raise ValueError(f"PT32 tensor of shape {tuple(self.t.shape)} does not hold {self.pts} points x {self.F} "
+                             f"features per task (expected {want})")
+
+    @property
+    def n_tasks(self) -> int:
+        return self.t.shape[0]
+
+
 # ---------------------------------------------------------------------------------------
 # low level: program assembly + launch
 # ---------------------------------------------------------------------------------------
@@ -531,6 +553,22 @@ class Chain:
         self.grad_enabled = torch.is_grad_enabled()
         outs = _ChainFn.apply(self, *[t for t in self.tensors])
         return outs
+
+    def run_pt(self, as_weights: bool = False) -> PTensor:
+        """Declare cur as the PT32 output, execute, and return it as a :class:`PTensor`.  ``as_weights``: a
+        later attention chain streams these activations as per-task weights (keys / values), so the
+        feature-major copy -- and in the bf16 compute mode the two bf16 images -- are produced by the same
+        launch and travel with the result."""
+        F = self.F
+        self.output_pt()
+        imgs = as_weights and COMPUTE_DTYPE == "bf16"
+        if as_weights:
+            self.store_tr()
+        if imgs:
+            self.store_bf16_images()
+        outs = self.run()
+        return PTensor(outs[0], self.pts, F, tr=outs[1] if as_weights else None,
+                       img=(outs[2], outs[3]) if imgs else None)
 
 
 class _ChainFn(torch.autograd.Function):

@@ -28,7 +28,7 @@ from torch.distributions import Independent, Normal
 from . import functional as FN
 from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, SelfAttention, get_attender,
                             merge_flat_input)
-from .chain import Chain, pad32
+from .chain import Chain, PTensor, pad32
 
 __all__ = ["NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP",
            "MultivariateNormalDiag"]
@@ -43,11 +43,6 @@ def MultivariateNormalDiag(loc, scale_diag):
 
 def _q_z_scale(z_scale):
     return 0.1 + 0.9 * torch.sigmoid(z_scale)
-
-
-def _rows_mlp(mlp: MLP, x: torch.Tensor) -> torch.Tensor:
-    """Row-wise MLP on a small [rows, F] tensor (per-task quantities)."""
-    return mlp(x)
 
 
 class NeuralProcessFamily(nn.Module, abc.ABC):
@@ -141,30 +136,17 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
     # ------------------------------------------------------------------ PT-level stages
     _attentive = False  # attentive subclasses also keep feature-major copies of keys / values
 
-    def _xenc_pt(self, X, with_tr=False):
+    def _xenc_pt(self, X, with_tr=False) -> PTensor:
         B, P, dx = X.shape
         ch = Chain(B, P, X.device)
         ch.input_rows(X.contiguous(), dx)
-        from . import chain as _chain
+        return self.x_encoder.append_to(ch).run_pt(as_weights=with_tr)
 
-        self.x_encoder.append_to(ch).output_pt()
-        imgs = with_tr and _chain.COMPUTE_DTYPE == "bf16"
-        if with_tr:
-            ch.store_tr()
-        if imgs:
-            ch.store_bf16_images()
-        outs = ch.run()
-        if with_tr:
-            outs[0]._npf_tr = outs[1]  # same activations, [task][feature][point]
-        if imgs:
-            outs[0]._npf_img = (outs[2], outs[3])  # bf16 row / transposed images for the attention chain
-        return outs[0]
-
-    def _xyenc_pt(self, X_enc_pt, Y, B, P):
-        """Per-point XY encoding (the per-point part of encode_globally) -> PT32 [B, P, r]."""
-        ch = Chain(B, P, Y.device)
+    def _xyenc_pt(self, X_enc: PTensor, Y) -> PTensor:
+        """Per-point XY encoding (the per-point part of encode_globally) -> [B, P, r]."""
+        ch = Chain(X_enc.n_tasks, X_enc.pts, Y.device)
         ch.input_rows(Y.contiguous(), self.y_dim)
-        return self.xy_encoder.run_pt(ch, X_enc_pt, B, P, with_tr=self._attentive)
+        return self.xy_encoder.run_pt(ch, X_enc.t, X_enc.n_tasks, X_enc.pts, with_tr=self._attentive)
 
     def _head(self, suff, Y_trgt, B, T):
         n_rows = suff.shape[0]
@@ -181,12 +163,12 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         """decoder(X_trgt_enc, R_trgt) when R_trgt is one vector per (z-sample, task)
         (np.py:107-110,161: the reference expands it over the targets and recomputes the
         resizer per target; here the resizer runs once per task)."""
-        resized = _rows_mlp(self.decoder.resizer, vec)  # [n_rows, r]
+        resized = self.decoder.resizer(vec)  # [n_rows, r]
         Fp = pad32(self.r_dim)
         if resized.shape[1] != Fp:
             resized = torch.nn.functional.pad(resized, (0, Fp - resized.shape[1]))
-        ch = Chain(n_rows, T, Xt_pt.device)
-        ch.input_pt(Xt_pt, self.x_transf_dim, modulus=(B if n_rows != B else 0))
+        ch = Chain(n_rows, T, Xt_pt.t.device)
+        ch.input_pt(Xt_pt.t, self.x_transf_dim, modulus=(B if n_rows != B else 0))
         ch.add_taskvec(resized.contiguous(), relu=True)
         self.decoder.flat_module.append_to(ch).output_rows()
         return ch.run()[0]
@@ -332,19 +314,19 @@ class CNP(NeuralProcessFamily):
         B, C, _ = X_cntxt.shape
         if C == 0:
             return torch.zeros(B, 1, self.r_dim, device=X_cntxt.device)
-        return self._encode_globally_pt(FN.pack_pt(X_cntxt), Y_cntxt, B, C)
+        return self._encode_globally_pt(PTensor(FN.pack_pt(X_cntxt), C, self.x_transf_dim), Y_cntxt, B, C)
 
     def trgt_dependent_representation(self, _, __, R, X_trgt):
         B, T, _ = X_trgt.shape
         return R.expand(B, T, self.r_dim).unsqueeze(0)
 
     # fused path
-    def _encode_globally_pt(self, X_enc_pt, Y, B, P):
+    def _encode_globally_pt(self, X_enc, Y, B, P):
         """-> row-major R [B, 1, r] (np.py:86-101)."""
         if P == 0:
             return torch.zeros(B, 1, self.r_dim, device=Y.device)
-        R_pts = self._xyenc_pt(X_enc_pt, Y, B, P)
-        return FN.mean_agg(R_pts, P, self.r_dim)[:, : self.r_dim].reshape(B, 1, self.r_dim)
+        R_pts = self._xyenc_pt(X_enc, Y)
+        return FN.mean_agg(R_pts.t, R_pts.pts, self.r_dim)[:, : self.r_dim].reshape(B, 1, self.r_dim)
 
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
         return self._decode_taskvec(Xt_pt, R.reshape(B, self.r_dim), B, T, B)
@@ -430,42 +412,41 @@ class AttnCNP(NeuralProcessFamily):
         return R_trgt.unsqueeze(0)
 
     # fused path
-    def _encode_globally_pt(self, X_enc_pt, Y, B, P):
-        """-> PT32 R_cntxt [B, P, r] (attnnp.py:105-116); None when there is no context."""
+    def _encode_globally_pt(self, X_enc, Y, B, P):
+        """-> R_cntxt [B, P, r] as a PTensor (attnnp.py:105-116); None when there is no context."""
         if P == 0:
             return None
-        return self._xyenc_pt(X_enc_pt, Y, B, P)
+        return self._xyenc_pt(X_enc, Y)
 
     def _attend_into(self, ch, Xc_pt, R, Xt_pt, C, T):
         """cur of ``ch`` <- attention of the targets over the context (attnnp.py:118-131): fused into
         the chain while a score row fits the registers, blocked (attention_long.py) beyond that."""
-        k_tr, v_tr = getattr(Xc_pt, "_npf_tr", None), getattr(R, "_npf_tr", None)
         from . import chain as _chain
 
         if not isinstance(self.attender, DotAttender):  # learned projections: its own launches
-            ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T), self.r_dim)
+            ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T), self.r_dim)
         elif _chain.COMPUTE_DTYPE == "bf16":
-            k_img, v_img = getattr(Xc_pt, "_npf_img", None), getattr(R, "_npf_img", None)
-            if k_img is not None and v_img is not None and self.attender.fits_fused(C):
+            if Xc_pt.img is not None and R.img is not None and self.attender.fits_fused(C):
                 # bf16 compute mode with bf16 images of keys / values: attention and decoder in one bf16 chain
-                ch.input_pt(Xt_pt, self.x_transf_dim)
-                self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr, keys_img=k_img, values_img=v_img)
+                ch.input_pt(Xt_pt.t, self.x_transf_dim)
+                self.attender.append_to(ch, Xc_pt.t, R.t, C, keys_tr=Xc_pt.tr, values_tr=R.tr, keys_img=Xc_pt.img,
+                                        values_img=R.img)
             else:  # the attention keeps an fp32 launch, the decoder chain behind it is bf16
-                ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T, keys_tr=k_tr, values_tr=v_tr), self.r_dim)
+                ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, keys_tr=Xc_pt.tr, values_tr=R.tr), self.r_dim)
         elif self.attender.fits_fused(C):
-            ch.input_pt(Xt_pt, self.x_transf_dim)
-            self.attender.append_to(ch, Xc_pt, R, C, keys_tr=k_tr, values_tr=v_tr)
+            ch.input_pt(Xt_pt.t, self.x_transf_dim)
+            self.attender.append_to(ch, Xc_pt.t, R.t, C, keys_tr=Xc_pt.tr, values_tr=R.tr)
         else:
-            ch.input_pt(self.attender.attend_pt(Xt_pt, Xc_pt, R, C, T, keys_tr=k_tr, values_tr=v_tr), self.r_dim)
+            ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, keys_tr=Xc_pt.tr, values_tr=R.tr), self.r_dim)
         return ch
 
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
-        ch = Chain(B, T, Xt_pt.device, wg_per_task=True)
+        ch = Chain(B, T, Xt_pt.t.device, wg_per_task=True)
         if C == 0:
-            ch.input_pt(torch.zeros_like(Xt_pt), self.r_dim)
+            ch.input_pt(torch.zeros_like(Xt_pt.t), self.r_dim)
         else:
             self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
-        self.decoder.append_to(ch, x1_pt=Xt_pt).output_rows()
+        self.decoder.append_to(ch, x1_pt=Xt_pt.t).output_rows()
         return ch.run()[0]
 
 
@@ -490,19 +471,11 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
             return torch.zeros(B, 1, self.r_dim, device=R.device)
         return FN.mean_agg(FN.pack_pt(R), C, self.r_dim)[:, : self.r_dim].reshape(B, 1, self.r_dim)
 
-    def _lat_input(self, R_pt, B):
-        if R_pt is None:
+    def _lat_input(self, R: Optional[PTensor], B):
+        """attnnp.py:172-181: the latent path pools the per-point representation (its own point count)."""
+        if R is None:
             return torch.zeros(B, 1, self.r_dim, device=self.r_z_merger.weight.device)
-        pts = self._pts_of[id(R_pt)]
-        return FN.mean_agg(R_pt, pts, self.r_dim)[:, : self.r_dim].reshape(B, 1, self.r_dim)
-
-    def _encode_globally_pt(self, X_enc_pt, Y, B, P):
-        R = AttnCNP._encode_globally_pt(self, X_enc_pt, Y, B, P)
-        if R is not None:
-            if not hasattr(self, "_pts_of"):
-                self._pts_of = {}
-            self._pts_of = {id(R): P, **{k: v for k, v in list(self._pts_of.items())[-3:]}}
-        return R
+        return FN.mean_agg(R.t, R.pts, self.r_dim)[:, : self.r_dim].reshape(B, 1, self.r_dim)
 
     def trgt_dependent_representation(self, X_cntxt, z_samples, R, X_trgt):
         B, T, _ = X_trgt.shape
@@ -513,7 +486,7 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
 
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
         n_z = z_samples.size(0)
-        dev = Xt_pt.device
+        dev = Xt_pt.t.device
         W, b, r = self.r_z_merger.weight, self.r_z_merger.bias, self.r_dim
         # the latent half of merge_r_z is constant per (z-sample, task): a per-task bias
         rows = n_z * B
@@ -523,13 +496,13 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
         if n_z == 1:
             ch = Chain(B, T, dev, wg_per_task=True)
             if C == 0:
-                ch.input_pt(torch.zeros_like(Xt_pt), r)
+                ch.input_pt(torch.zeros_like(Xt_pt.t), r)
             else:
                 self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
             mod = 0
         else:
             if C == 0:
-                R_det = torch.zeros_like(Xt_pt)
+                R_det = torch.zeros_like(Xt_pt.t)
             else:
                 cha = Chain(B, T, dev, wg_per_task=True)
                 self._attend_into(cha, Xc_pt, R, Xt_pt, C, T).output_pt()
@@ -538,5 +511,5 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
             ch.input_pt(R_det, r, modulus=B)
             mod = B
         ch.linear(W[:, :r], zb, relu=True, bias_per_task=True)
-        self.decoder.append_to(ch, x1_pt=Xt_pt, x1_modulus=mod).output_rows()
+        self.decoder.append_to(ch, x1_pt=Xt_pt.t, x1_modulus=mod).output_rows()
         return ch.run()[0]

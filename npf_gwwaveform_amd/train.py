@@ -13,6 +13,7 @@ import os
 from typing import Optional
 
 import torch
+import torch.distributed as dist
 
 from .parallel import BucketedGradReducer, FlatParameters
 
@@ -61,12 +62,44 @@ class Trainer:
         self.flat = FlatParameters(model.parameters())
         self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
         self.use_graph = bool(use_graph) and self.flat.flat.is_cuda and self.reducer.world == 1
+        if self.use_graph and hasattr(getattr(model, "n_z_samples_train", None), "rvs"):
+            raise ValueError("use_graph=True freezes the step at capture time, but this model draws a random number of "
+                             "latent samples per forward (n_z_samples_train is a random variable)")
         # one fused kernel per step on the flat buffer (the default implementation is ~8 launches)
         self.opt = torch.optim.Adam([self.flat.flat], lr=lr, fused=self.flat.flat.is_cuda, capturable=self.use_graph)
         self.model.train()
         self.criterion.train()
         self._graph = None
         self._eager_steps = 0
+        self.sync_replicas()
+
+    def sync_replicas(self) -> None:
+        """Data-parallel replicas must start from the same weights and optimizer state: rank 0's flat
+        parameter buffer (and Adam moments / step count, once they exist) are broadcast to every rank.
+        Called at construction and after a checkpoint load; a no-op on a single rank."""
+        if self.reducer.world <= 1:
+            return
+        if not dist.is_initialized():
+            raise RuntimeError(f"Trainer(world={self.reducer.world}) needs an initialised torch.distributed process group")
+        group = self.reducer.group
+        dist.broadcast(self.flat.flat.data, src=0, group=group)
+        have = torch.tensor([1.0 if self.opt.state.get(self.flat.flat) else 0.0], device=self.flat.flat.device)
+        dist.broadcast(have, src=0, group=group)
+        if have.item() > 0:
+            st = self.opt.state[self.flat.flat]
+            if not st:  # rank 0 resumed from a checkpoint, this rank did not: allocate the same state
+                st["step"] = torch.zeros((), dtype=torch.float32, device=self.flat.flat.device)
+                st["exp_avg"] = torch.zeros_like(self.flat.flat.data)
+                st["exp_avg_sq"] = torch.zeros_like(self.flat.flat.data)
+            for key in ("exp_avg", "exp_avg_sq"):
+                dist.broadcast(st[key], src=0, group=group)
+            step = st["step"] if torch.is_tensor(st["step"]) else torch.tensor(float(st["step"]))
+            step_dev = step.to(self.flat.flat.device, torch.float32).reshape(1).clone()
+            dist.broadcast(step_dev, src=0, group=group)
+            if torch.is_tensor(st["step"]):
+                st["step"].copy_(step_dev.reshape(()).to(st["step"].device))
+            else:
+                st["step"] = float(step_dev.item())
 
     def step(self, batch: dict) -> torch.Tensor:
         if self.use_graph:
@@ -140,5 +173,6 @@ class Trainer:
                 self.opt.load_state_dict(torch.load(opt_path, map_location=self.flat.flat.device, weights_only=True))
             except (ValueError, KeyError, RuntimeError) as e:  # e.g. skorch's per-tensor optimizer state
                 raise ValueError(f"{opt_path} does not hold this Trainer's flat Adam state: {e}") from e
+        self.sync_replicas()  # (ranks that loaded nothing, or something else, follow rank 0)
         hist = os.path.join(dirname, "history.json")
         return json.load(open(hist)) if os.path.exists(hist) else []

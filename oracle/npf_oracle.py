@@ -11,6 +11,15 @@ to reproduce them bit-for-bit on the small cases (G1/G2/G6/G7) and within the st
 fp32 tolerance on the large ones (G3-G5; the last-ulp level there depends on the BLAS
 blocking).
 
+bf16 emulation (``matmul_mode("bf16")``, BASELINE config 3): the same restatement with every
+contraction's operands rounded to bfloat16 (round-to-nearest-even) exactly where the HIP kernels of
+the bf16 compute mode round them, fp32 accumulation, everything else in fp32 -- forward AND backward
+(hand-written autograd functions, because the backward contractions round *their* operands too).
+The reference has no bf16 path, so this mode is not pinned by reference vectors: it is the pinned fp32
+restatement plus the rounding points DESIGN.md section 8 states, and it exists so that the bf16
+kernels face a full-tensor gate instead of a cosine.  It models the scaled-dot / mean-aggregation
+family with at most 256 features and 256 context points (what configs 3 and 4 run).
+
 Style: functional and state_dict driven -- every function takes the flat parameter
 dict (reference key names, e.g. ``decoder.flat_module.linears.0.weight``) so that the
 same dict drives the reference, this oracle and the HIP path.  Every function cites the
@@ -80,27 +89,125 @@ class OracleConfig:
 RELU_MARGINS = None
 
 
+# --------------------------------------------------------------------------------------
+# bf16 emulation of the HIP bf16 compute mode
+# --------------------------------------------------------------------------------------
+MATMUL_MODE = "fp32"
+
+
+class matmul_mode:
+    """``with matmul_mode("bf16"): ...`` -- emulate the HIP path's bf16 compute mode."""
+
+    def __init__(self, mode: str):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        global MATMUL_MODE
+        self.prev, MATMUL_MODE = MATMUL_MODE, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global MATMUL_MODE
+        MATMUL_MODE = self.prev
+
+
+def _r16(t: torch.Tensor) -> torch.Tensor:
+    """Round to bfloat16 (nearest even, what v_cvt_pk_bf16_f32 does) and back to fp32."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearBf16(torch.autograd.Function):
+    """y = bf16(x) bf16(W)^T + b with fp32 accumulation (chain_kernel BF16 instance: the weight image is
+    rounded once per step, the layer input at the MFMA, the bias initialises the fp32 accumulator).
+    Backward as the dgrad chain + wgrad launch do it: dZ is rounded at the dgrad MFMA and in the PT16
+    buffer the wgrad kernel reads, so dx = bf16(dy) bf16(W), dW = bf16(dy)^T bf16(x); db sums the dZ buffer
+    as stored -- PT16 (rounded) unless the same buffer also carries an addend's gradient back to autograd
+    (then it is an fp32 tensor: ``db_rounded=False``)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, db_rounded):
+        xr, Wr = _r16(x), _r16(W)
+        ctx.save_for_backward(xr, Wr)
+        ctx.has_b, ctx.db_rounded = b is not None, db_rounded
+        y = xr @ Wr.t()
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, Wr = ctx.saved_tensors
+        N, K = Wr.shape
+        dyr = _r16(dy)
+        dx = dyr @ Wr
+        dW = dyr.reshape(-1, N).t() @ xr.reshape(-1, K)
+        db = (dyr if ctx.db_rounded else dy).reshape(-1, N).sum(0) if ctx.has_b else None
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, db_rounded: bool = True):
+    """``F.linear`` of the reference, or its bf16-mode emulation."""
+    if MATMUL_MODE == "bf16":
+        return _LinearBf16.apply(x, W, b, db_rounded)
+    return F.linear(x, W, b)
+
+
+class _ScaledotBf16(torch.autograd.Function):
+    """softmax(bf16(q) bf16(K)^T / sqrt(d)) in fp32, then bf16(P) bf16(V) (two per-task-weight LINEARs of the
+    bf16 chain with the in-register softmax between them).  Backward: dP = bf16(dO) bf16(V)^T; the softmax
+    backward uses the SAVED probabilities, which are a PT16 tensor, i.e. bf16(P): dS = scale P16 (dP - <dP, P16>);
+    dQ = bf16(dS) bf16(K), dK = bf16(dS)^T bf16(q), dV = bf16(P)^T bf16(dO)."""
+
+    @staticmethod
+    def forward(ctx, keys, queries, values):
+        kr, qr, vr = _r16(keys), _r16(queries), _r16(values)
+        scale = 1.0 / math.sqrt(queries.size(-1))
+        s = torch.einsum("bkd,bqd->bqk", kr, qr)
+        m = s.max(dim=-1, keepdim=True).values
+        e = torch.exp((s - m) * scale)
+        P = e / e.sum(-1, keepdim=True)
+        Pr = _r16(P)
+        ctx.save_for_backward(kr, qr, vr, Pr)
+        ctx.scale = scale
+        return torch.bmm(Pr, vr)
+
+    @staticmethod
+    def backward(ctx, dO):
+        kr, qr, vr, Pr = ctx.saved_tensors
+        dOr = _r16(dO)
+        dP = torch.bmm(dOr, vr.transpose(1, 2))
+        dS = ctx.scale * Pr * (dP - (dP * Pr).sum(-1, keepdim=True))
+        dSr = _r16(dS)
+        dQ = torch.bmm(dSr, kr)
+        dK = torch.bmm(dSr.transpose(1, 2), qr)
+        dV = torch.bmm(Pr.transpose(1, 2), dOr)
+        return dK, dQ, dV
+
+
 def _relu(v: torch.Tensor) -> torch.Tensor:
     if RELU_MARGINS is not None and v.numel():
         RELU_MARGINS.append(float(v.detach().abs().min()))
     return torch.relu(v)
 
 
-def mlp(params: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+def mlp(params: Params, prefix: str, x: torch.Tensor, out_db_rounded: bool = True) -> torch.Tensor:
     """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU, no dropout, no
-    residual: to_hidden -> relu -> [linears.i -> relu]* -> out (no activation)."""
-    h = _relu(F.linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
+    residual: to_hidden -> relu -> [linears.i -> relu]* -> out (no activation).
+    (``out_db_rounded``: bf16 emulation only, see ``_LinearBf16``.)"""
+    h = _relu(linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
     i = 0
     while f"{prefix}.linears.{i}.weight" in params:
-        h = _relu(F.linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
+        h = _relu(linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
         i += 1
-    return F.linear(h, params[f"{prefix}.out.weight"], params[f"{prefix}.out.bias"])
+    return linear(h, params[f"{prefix}.out.weight"], params[f"{prefix}.out.bias"], out_db_rounded)
 
 
-def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor, fused_addend: bool = True) -> torch.Tensor:
     """``MergeFlatInputs.forward`` with ``is_sum_merge=True``
-    (npf/architectures/encoders.py:175-183): flat(relu(x1 + resizer(x2)))."""
-    x2 = mlp(params, f"{prefix}.resizer", x2)
+    (npf/architectures/encoders.py:175-183): flat(relu(x1 + resizer(x2))).
+    (``fused_addend``: bf16 emulation only -- x1 enters the resizer's last layer as its addend inside one
+    chain, whose dZ buffer is then an fp32 tensor.)"""
+    x2 = mlp(params, f"{prefix}.resizer", x2, out_db_rounded=not fused_addend)
     return mlp(params, f"{prefix}.flat_module", _relu(x1 + x2))
 
 
@@ -108,6 +215,8 @@ def scaledot_attend(keys: torch.Tensor, queries: torch.Tensor, values: torch.Ten
     """``get_attender("scaledot")`` = ``DotAttender`` on ``BaseAttender.forward``
     (npf/architectures/attention.py:129-164,204-220): softmax(Q K^T / sqrt(d)) V, single
     head, no learned projections, no resizer (value_size == out_size on this path)."""
+    if MATMUL_MODE == "bf16":
+        return _ScaledotBf16.apply(keys, queries, values)
     logits = torch.einsum("bkd,bqd->bqk", keys, queries) / math.sqrt(queries.size(-1))
     attn = logits.softmax(dim=-1)
     return torch.bmm(attn, values)
@@ -206,6 +315,14 @@ def infer_latent_dist(cfg: OracleConfig, params: Params, R: torch.Tensor) -> Tup
 
 def merge_r_z(cfg: OracleConfig, params: Params, R: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     """``merge_r_z`` (npf/neuralproc/base.py:554-575)."""
+    if MATMUL_MODE == "bf16":
+        # the HIP path never materialises the concatenation: the latent half is a per-(sample, task) bias
+        # computed once per row of z (``z`` must come in un-expanded, [n_z, B, 1, z]) and added in fp32
+        W, r = params["r_z_merger.weight"], cfg.r_dim
+        zb = linear(z, W[:, r:], params["r_z_merger.bias"])
+        Re = R if R.dim() == z.dim() else R.unsqueeze(0)
+        Re = Re.expand(z.shape[0], *Re.shape[1:])  # the deterministic half is contracted per (sample, task, point) row
+        return torch.relu(linear(Re, W[:, :r], None) + zb)
     if R.shape != z.shape:
         R = R.unsqueeze(0).expand(*z.shape[:-1], cfg.r_dim)
     return torch.relu(F.linear(torch.cat((R, z), dim=-1), params["r_z_merger.weight"], params["r_z_merger.bias"]))
@@ -224,7 +341,7 @@ def trgt_dependent_representation(cfg, params, Xc_enc, z_samples, R, Xt_enc) -> 
         else:
             R_trgt = z_samples
             if cfg.z_dim != cfg.r_dim:
-                R_trgt = F.linear(R_trgt, params["reshaper_z.weight"], params["reshaper_z.bias"])
+                R_trgt = linear(R_trgt, params["reshaper_z.weight"], params["reshaper_z.bias"])
         return R_trgt.expand(n_z, B, T, cfg.r_dim)
     # attentive
     if Xc_enc.shape[1] == 0:
@@ -234,6 +351,8 @@ def trgt_dependent_representation(cfg, params, Xc_enc, z_samples, R, Xt_enc) -> 
     if cfg.kind == "AttnCNP":
         return R_det.unsqueeze(0)
     n_z = z_samples.size(0)
+    if MATMUL_MODE == "bf16":
+        return merge_r_z(cfg, params, R_det.unsqueeze(0), z_samples)
     z = z_samples.expand(n_z, B, T, cfg.z_dim)
     return merge_r_z(cfg, params, R_det, z)
 
@@ -242,7 +361,13 @@ def decode(cfg: OracleConfig, params: Params, Xt_enc: torch.Tensor, R_trgt: torc
     """``NeuralProcessFamily.decode`` (npf/neuralproc/base.py:327-367) -> (loc, scale),
     each [n_z, B, T, y_dim]; homoskedastic pooling per
     npf/neuralproc/helpers.py:21-32."""
-    suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt)
+    if MATMUL_MODE == "bf16" and not cfg.is_attentive:
+        # mean-aggregation models: R_trgt is one vector per (sample, task) expanded over the targets; the HIP
+        # path resizes it once per task (its own small chain) and adds the result to every target in fp32
+        x2 = mlp(params, "decoder.resizer", R_trgt[..., :1, :])
+        suff = mlp(params, "decoder.flat_module", _relu(Xt_enc + x2))
+    else:
+        suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt)
     loc, raw = suff.split(cfg.y_dim, dim=-1)
     scale = p_y_scale_transform(raw)
     if not cfg.is_heteroskedastic:

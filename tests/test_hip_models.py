@@ -435,7 +435,8 @@ def test_training_reduces_the_loss(dtype):
 
 def test_graph_captured_step_equals_eager_step():
     """Trainer(use_graph=True): the step replayed from a captured HIP graph leaves the same parameters as
-    the eager step (same kernels in the same order), for a model with attention and a latent path."""
+    the eager step (same kernels in the same order), for an attentive deterministic model (AttnCNP); the
+    latent case follows below."""
     import warnings
 
     import npf_gwwaveform_amd as A
@@ -456,3 +457,94 @@ def test_graph_captured_step_equals_eager_step():
     np.testing.assert_allclose(l_g, l_e, rtol=1e-6)
     for k in p_e:
         assert torch.allclose(p_g[k], p_e[k], rtol=1e-6, atol=1e-8), k
+
+
+def test_attnlnp_varying_context_sizes_track_the_oracle_every_step():
+    """One AttnLNP (is_q_zCct=True) trained for 20 steps with a different number of context AND target
+    points every step, garbage collection and allocator churn in between: q_zCc, q_zCct and the loss must
+    equal the oracle's at every step.  The latent path pools each per-point representation over ITS OWN
+    point count (attnnp.py:172-181) -- the count travels with the tensor (chain.PTensor), not through a
+    lookup keyed by the identity of a temporary."""
+    import gc
+
+    from oracle import npf_oracle as O
+
+    case = dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=8, T=16, is_q_zCct=True, n_z=1)
+    model = build_model(case, DEV, params=specs.make_params(case, seed=21))
+    crit = build_loss(case)
+    model.train()
+    crit.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    cfg = specs.cfg_of(case)
+    rng = np.random.Generator(np.random.Philox(5))
+    for step in range(20):
+        c = dict(case, C=int(rng.integers(1, 70)), T=int(rng.integers(2, 90)))
+        inp = specs.make_inputs(c, seed=900 + step)
+        dinp = {k: v.to(DEV) for k, v in inp.items()}
+        EpsIndependent.eps = dinp["eps"]
+        opt.zero_grad(set_to_none=True)
+        out = model(dinp["X_cntxt"], dinp["Y_cntxt"], dinp["X_trgt"], dinp["Y_trgt"])
+        loss = crit(out, dinp["Y_trgt"])
+        params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        ref = O.forward(cfg, params, inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"], eps=inp["eps"], n_z=1)
+        ref_loss = O.elbo_loss(ref, inp["Y_trgt"])
+        what = f"step {step} (C={c['C']}, T={c['T']})"
+        assert_close(out[2].base_dist.loc, ref["q_zCc"][0], what=f"q_zCc.loc {what}")
+        assert_close(out[2].base_dist.scale, ref["q_zCc"][1], what=f"q_zCc.scale {what}")
+        assert_close(out[3].base_dist.loc, ref["q_zCct"][0], what=f"q_zCct.loc {what}")
+        assert_close(out[0].base_dist.loc, ref["loc"], what=f"loc {what}")
+        np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=2e-5, err_msg=what)
+        loss.backward()
+        opt.step()
+        del out, loss
+        gc.collect()
+        junk = [torch.empty(int(rng.integers(1, 64)) * 1024, device=DEV) for _ in range(8)]  # allocator churn
+        del junk
+
+
+def test_graph_captured_step_equals_eager_step_latent_model():
+    """The same for an AttnLNP with the target-side latent encode (is_q_zCct=True, one latent sample): the
+    captured step replays the latent path (two mean aggregations with different point counts, the noise
+    draw of rsample) and leaves the parameters of the eager run, given the same noise."""
+    import warnings
+
+    import npf_gwwaveform_amd as A
+    from helpers import eps_latent_dist
+    from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
+
+    eps = torch.randn(1, 8, 1, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run(use_graph):
+        torch.manual_seed(3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = A.AttnLNP(1, 2, r_dim=64, is_q_zCct=True, n_z_samples_train=1, n_z_samples_test=1,
+                              LatentDistribution=eps_latent_dist).to(DEV)
+        EpsIndependent.eps = eps
+        tr = Trainer(model, A.ELBOLossLNPF(), lr=1e-3, world=1, use_graph=use_graph)
+        losses = [float(tr.step(synthetic_waveform_batch(8, 20, 50, 500 + i, DEV))) for i in range(9)]
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, tr
+
+    l_e, p_e, _ = run(False)
+    l_g, p_g, tr = run(True)
+    assert tr._graph is not None
+    np.testing.assert_allclose(l_g, l_e, rtol=1e-6)
+    for k in p_e:
+        assert torch.allclose(p_g[k], p_e[k], rtol=1e-6, atol=1e-8), k
+
+
+def test_graph_step_refuses_a_random_number_of_latent_samples():
+    """A scipy random variable as n_z_samples_train is drawn on the host every forward (base.py:478-486): a
+    captured graph would freeze one draw, so Trainer(use_graph=True) refuses such a model."""
+    import warnings
+
+    import scipy.stats
+
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd.train import Trainer
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = A.AttnLNP(1, 2, r_dim=32, n_z_samples_train=scipy.stats.randint(1, 4)).to(DEV)
+    with pytest.raises(ValueError, match="random"):
+        Trainer(model, A.NLLLossLNPF(), use_graph=True)

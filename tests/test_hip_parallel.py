@@ -1,0 +1,71 @@
+"""The data-parallel train step on real kernels (BASELINE config 4's code path): two ranks of
+the HIP ``Trainer`` on device 0 exchanging gradients over gloo must reproduce the single-process step on
+the global batch -- averaged flat gradient and post-Adam weights -- although every rank but 0 was built
+from different initial weights (``Trainer`` broadcasts rank 0's).  The reference has no distributed code
+(utils/train.py:163-164 trains on one device); the contract is the global-batch step."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from dp_cases import CASES, build, global_batch
+from helpers import EpsIndependent
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _single_process(case):
+    from npf_gwwaveform_amd.train import Trainer
+
+    model, crit = build(case, seed=0)
+    trainer = Trainer(model, crit, lr=1e-3, world=1)
+    batch = global_batch(case)
+    eps = batch.pop("eps", None)
+    losses, grads = [], []
+    for _ in range(case.get("steps", 2)):
+        if eps is not None:
+            EpsIndependent.eps = eps
+        losses.append(float(trainer.step(batch).item()))
+        grads.append(trainer.flat.flat_grad.detach().cpu().clone())
+    return losses, grads, trainer.flat.flat.detach().cpu().clone()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", list(CASES))
+def test_two_rank_trainer_equals_global_batch_step(name, tmp_path):
+    case, world, port = CASES[name], 2, _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / f"rank{r}.pt") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), str(port), outs[r], name],
+                              env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=500) == 0, "a data-parallel rank failed"
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    ref_losses, ref_grads, ref_w = _single_process(case)
+    res = [torch.load(o, weights_only=True) for o in outs]
+    # replicas agree bit for bit with each other (same averaged gradient, same Adam state)
+    assert torch.equal(res[0]["weights"], res[1]["weights"])
+    for s in range(len(ref_grads)):
+        assert torch.equal(res[0]["grads"][s], res[1]["grads"][s])
+        # the local losses are means over the local tasks: their mean is the global loss
+        mean_loss = sum(r["losses"][s] for r in res) / world
+        assert abs(mean_loss - ref_losses[s]) <= 2e-6 * abs(ref_losses[s]), (s, mean_loss, ref_losses[s])
+        g, want = res[0]["grads"][s].double(), ref_grads[s].double()
+        assert (g - want).abs().max() <= 1e-6 * want.abs().max(), (s, float((g - want).abs().max()), float(want.abs().max()))
+    # post-Adam weights after the steps: 1e-6 (absolute; lr = 1e-3, weights O(0.1))
+    d = (res[0]["weights"].double() - ref_w.double()).abs()
+    assert d.max() <= 1e-6, float(d.max())

@@ -16,7 +16,8 @@ from test_hip_sweep import _oracle
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 N_CASES = int(os.environ.get("NPF_STRESS", "0"))
-DTYPE = os.environ.get("NPF_STRESS_DTYPE", "fp32")  # "bf16": the bf16 compute mode against the fp32 oracle, loose bounds
+# "bf16": the bf16 compute mode against the oracle's bf16 emulation (oracle.matmul_mode), 2e-3 of max|ref| per tensor
+DTYPE = os.environ.get("NPF_STRESS_DTYPE", "fp32")
 
 
 def _random_case(rng: random.Random) -> dict:
@@ -41,11 +42,13 @@ def test_random_shapes_match_oracle():
     failures, ties = [], 0
     for i in range(N_CASES):
         case = _random_case(rng)
+        if DTYPE == "bf16" and (case.get("attention", "scaledot") != "scaledot" or case["C"] > 256):
+            continue  # (the bf16 emulation models the fused scaled-dot family; the rest keeps fp32 attention launches)
         try:
             params = specs.make_params(case, seed=100 + i)
             inp = specs.make_inputs(case, seed=200 + i)
             O.RELU_MARGINS = []
-            ref_p, ref_out, ref_loss = _oracle(case, inp, params)
+            ref_p, ref_out, ref_loss = _oracle(case, inp, params, mode=DTYPE)
             margin, O.RELU_MARGINS = min(O.RELU_MARGINS, default=1.0), None
             model = build_model(case, DEV, params=params)
             dinp = {k: v.to(DEV) for k, v in inp.items()}
@@ -63,39 +66,19 @@ def test_random_shapes_match_oracle():
                 loss.backward()
             finally:
                 A.set_compute_dtype("fp32")
-            if DTYPE == "bf16":
-                # bf16 products: bounded, not gated at the fp32 tolerance; gradients must point the same way
-                for key, got in (("loc", out[0].base_dist.loc), ("scale", out[0].base_dist.scale)):
-                    ref = ref_out[key].detach().double()
-                    err = float((got.detach().cpu().double() - ref).abs().max())
-                    assert err <= 6e-2 * float(ref.abs().max()) + 5e-3, (key, err, float(ref.abs().max()))
-                assert abs(loss.item() - ref_loss.item()) <= 3e-2 * abs(ref_loss.item()) + 0.5, (loss.item(), ref_loss.item())
-                few_points = min(case["B"] * case["T"] * case.get("n_z", 1), case["B"] * case["C"]) < 32
-                if margin < 2e-2 and few_points:
-                    # a ReLU pre-activation within bf16 rounding of zero: the rounded products may flip it, and with
-                    # a handful of points one flipped unit turns the gradients of the layers below (outputs and
-                    # loss were checked above; the fp32 run of the same case matches the oracle to 1e-5)
-                    ties += 1
-                    continue
-                for k, p in model.named_parameters():
-                    ref = ref_p[k].grad if ref_p[k].grad is not None else torch.zeros_like(ref_p[k])
-                    if p.grad is None or float(ref.abs().max()) == 0.0 or ref.numel() < 64:
-                        continue
-                    a, b = p.grad.cpu().double().reshape(-1), ref.double().reshape(-1)
-                    cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
-                    assert cos > 0.7, (k, cos)  # (gross errors only: tiny models have noisy bf16 gradients)
-                continue
-            assert_close(out[0].base_dist.loc, ref_out["loc"], what="loc")
-            assert_close(out[0].base_dist.scale, ref_out["scale"], what="scale")
-            np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=5e-5)
+            tol_out, tol_loss, tol_grad = (2e-3, 2e-3, 2e-3) if DTYPE == "bf16" else (1e-5, 5e-5, 2e-4)
+            assert_close(out[0].base_dist.loc, ref_out["loc"], tol=tol_out, what="loc")
+            assert_close(out[0].base_dist.scale, ref_out["scale"], tol=tol_out, what="scale")
+            np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=tol_loss)
             for k, p in model.named_parameters():
                 ref = ref_p[k].grad if ref_p[k].grad is not None else torch.zeros_like(ref_p[k])
                 got = p.grad if p.grad is not None else torch.zeros_like(p)
-                assert_close(got, ref, tol=2e-4, what=f"grad {k}")
+                assert_close(got, ref, tol=tol_grad, what=f"grad {k}")
         except Exception as e:  # collect, report all
-            if isinstance(e, AssertionError) and "grad" in repr(e) and margin < 2e-7:
-                # a ReLU pre-activation within fp32 rounding of zero: its derivative is decided by rounding
-                # noise, both gradients are valid fp32 results (forward outputs and loss were checked above)
+            if isinstance(e, AssertionError) and "grad" in repr(e) and margin < (2e-5 if DTYPE == "bf16" else 2e-7):
+                # a ReLU pre-activation within fp32 rounding of zero (bf16 mode: within the shift one flipped bf16
+                # rounding upstream causes): its derivative is decided by rounding noise, both gradients are
+                # valid results (forward outputs and loss were checked above)
                 ties += 1
                 continue
             failures.append((i, case, repr(e)[:300]))

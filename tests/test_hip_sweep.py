@@ -27,6 +27,10 @@ SWEEP = {
     "attncnp_r96": dict(kind="AttnCNP", r=96, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=37, T=70),
     "attncnp_r160_c255": dict(kind="AttnCNP", r=160, L_xy=2, L_dec=2, dx=2, dy=2, B=2, C=255, T=129),
     "attncnp_r256_c256_t100": dict(kind="AttnCNP", r=256, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=256, T=100),
+    # BASELINE config 2's model and point counts at batch 2: EVERY gradient tensor in full (the golden vectors
+    # g3 / g4 of this size only store norms and 64-entry heads)
+    "attncnp_c2_full": dict(kind="AttnCNP", r=256, L_xy=4, L_dec=4, dx=1, dy=2, B=2, C=256, T=1024),
+    "attnlnp_c2_full": dict(kind="AttnLNP", r=256, L_xy=4, L_dec=4, dx=1, dy=2, B=2, C=256, T=1024, is_q_zCct=True, n_z=1),
     "attncnp_r44": dict(kind="AttnCNP", r=44, L_xy=2, L_dec=2, dx=1, dy=1, B=2, C=3, T=9),
     "attnlnp_nz3_r64": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=40, T=48, is_q_zCct=True, n_z=3),
     # more context points than one fused score row holds: blocked softmax (attention_long.py)
@@ -42,13 +46,15 @@ SWEEP = {
 }
 
 
-def _oracle(case, inp, params):
+def _oracle(case, inp, params, mode="fp32"):
+    """The oracle's train step; ``mode="bf16"``: its emulation of the bf16 compute mode."""
     cfg = specs.cfg_of(case)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    out = O.forward(cfg, p, inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"], eps=inp.get("eps"),
-                    n_z=case.get("n_z", 1), training=True)
-    loss = LOSSES[specs.loss_name(case)](out, inp["Y_trgt"])
-    loss.backward()
+    with O.matmul_mode(mode):
+        out = O.forward(cfg, p, inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"], eps=inp.get("eps"),
+                        n_z=case.get("n_z", 1), training=True)
+        loss = LOSSES[specs.loss_name(case)](out, inp["Y_trgt"])
+        loss.backward()
     return p, out, loss
 
 
