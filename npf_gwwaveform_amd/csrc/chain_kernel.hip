@@ -25,7 +25,12 @@
 // (attention.py:129-164,204-220), merge_r_z (neuralproc/base.py:554-575) and their autograd.
 #include <type_traits>
 
+#include "chain16.hpp"
 #include "npf_common.hpp"
+
+#ifndef NPF_BF16_PREFETCH
+#define NPF_BF16_PREFETCH 3  // bf16 instance: k-steps of fragment reads in flight ahead of the MFMAs
+#endif
 
 namespace npf {
 
@@ -469,6 +474,40 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 #pragma unroll
   for (int t = 0; t < 4; ++t) addr[t] = lds0 + (((t ^ (ps >> 2)) << 6) | ((w.g ^ (ps & 3)) << 4));
   constexpr int kRowBlk = 16 * Kp * 4;
+  if constexpr (BF16) {
+    // bf16: a k-step is only two 16-cycle MFMAs, far less than the LDS latency under load (8 waves per CU reading): the
+    // fragment reads run kPf k-steps ahead of the MFMAs (kPf + 1 register sets), every wait counts what may stay in flight
+    constexpr int kPf = NPF_BF16_PREFETCH;
+    static_assert(kPf >= 1 && kPf <= 3 && KB16S > kPf, "prefetch depth");
+    f32x4 fq[kPf + 1][2];
+#define NPF_RD(set, kbn)                                                                \
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"         \
+               : "=&v"(fq[set][0]), "=&v"(fq[set][1])                                   \
+               : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256), "n"(((kbn) >> 2) * 256 + kRowBlk));
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) { NPF_RD(i, i) }
+#pragma unroll
+    for (int kb = 0; kb < KB16S; ++kb) {
+      const int c = kb % (kPf + 1);
+      if (kb + kPf < KB16S) {
+        NPF_RD((kb + kPf) % (kPf + 1), kb + kPf)
+        if constexpr (kPf == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
+        else if constexpr (kPf == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
+      } else {
+        const int left = KB16S - 1 - kb;  // k-steps still in flight behind this one
+        if (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
+        else if (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][0]), curb[kb], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][1]), curb[kb], acc1, 0, 0, 0);
+      side(kb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef NPF_RD
+    return;
+  }
   f32x4 fr[2][2] = {};
   asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:%3"
                : "=&v"(fr[0][0]), "=&v"(fr[0][1])
@@ -1252,6 +1291,11 @@ extern "C" int npf_chain_run(const npf_program_t* prog, void* stream) {
                                     (o.s0 & 3)))
         return NPF_EINVAL;
     }
+    // reserved[1] == 4 (NPF_FORCE_WG=4, experiments): the one-wave-per-SIMD bf16 interpreter of chain16_kernel.hip
+    // (correct, parity-tested, and slower than the instance below: DESIGN.md section 8)
+    if (g.reserved[1] == 4) return npf16_chain_launch(g, stream);
+    // (a 128-point paired bf16 instance <16, 8, ..., true> -- half the slab DMA per MFMA -- was measured: bare 8-layer
+    // chain 2.27 vs 2.08 ms, config-3 step 15.7 vs 15.9 ms: no gain, not kept)
     hipLaunchKernelGGL((npf::chain_kernel<16, 4, false, 8, 8, true>), dim3((unsigned)grid_for(2)), dim3(256), 0,
                        (hipStream_t)stream, g);
     NPF_CHECK_LAUNCH();

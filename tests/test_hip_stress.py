@@ -16,7 +16,8 @@ from test_hip_sweep import _oracle
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 N_CASES = int(os.environ.get("NPF_STRESS", "0"))
-# "bf16": the bf16 compute mode against the oracle's bf16 emulation (oracle.matmul_mode), 2e-3 of max|ref| per tensor
+# "bf16": the bf16 compute mode against the oracle's bf16 emulation (oracle.matmul_mode), with the relative-L2 / max-norm
+# gate of tests/test_hip_bf16.py (what that tolerance is made of is explained there)
 DTYPE = os.environ.get("NPF_STRESS_DTYPE", "fp32")
 
 
@@ -66,7 +67,21 @@ def test_random_shapes_match_oracle():
                 loss.backward()
             finally:
                 A.set_compute_dtype("fp32")
-            tol_out, tol_loss, tol_grad = (2e-3, 2e-3, 2e-3) if DTYPE == "bf16" else (1e-5, 5e-5, 2e-4)
+            if DTYPE == "bf16":
+                from test_hip_bf16 import TOL_GRAD_L2, TOL_MAX, TOL_OUT_L2, _check
+
+                _check(out[0].base_dist.loc, ref_out["loc"], TOL_OUT_L2, TOL_MAX, "loc")
+                _check(out[0].base_dist.scale, ref_out["scale"], TOL_OUT_L2, TOL_MAX, "scale")
+                np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=1e-3)
+                few_rows = case["B"] * case.get("n_z", 1) * min(case["C"], case["T"]) < 64
+                for k, p in model.named_parameters():
+                    ref = ref_p[k].grad if ref_p[k].grad is not None else torch.zeros_like(ref_p[k])
+                    got = p.grad if p.grad is not None else torch.zeros_like(p)
+                    if float(ref.abs().max()) > 0:
+                        # (a contraction over a handful of rows: one flipped bf16 rounding is a visible share of it)
+                        _check(got, ref, 1e-1 if few_rows else TOL_GRAD_L2, 2.5e-1 if few_rows else TOL_MAX, f"grad {k}")
+                continue
+            tol_out, tol_loss, tol_grad = 1e-5, 5e-5, 2e-4
             assert_close(out[0].base_dist.loc, ref_out["loc"], tol=tol_out, what="loc")
             assert_close(out[0].base_dist.scale, ref_out["scale"], tol=tol_out, what="scale")
             np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=tol_loss)
