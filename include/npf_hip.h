@@ -17,6 +17,8 @@
  *                        pool_and_replicate_middle        npf/neuralproc/helpers.py:21-32,
  *                        sum_log_prob                     npf/losses.py:18-24
  *   npf_gauss_head_bwd   autograd of the above
+ *   npf_mc_objective_fwd/bwd  mean / logsumexp / SUMO over the latent samples
+ *                                                         npf/losses.py:146,197-200,262-274
  *   npf_mean_agg_fwd/bwd torch.mean(R_cntxt, dim=1)       npf/neuralproc/np.py:95, attnnp.py:181
  *   npf_pack_pt/unpack_pt  layout change at the module boundary (no reference counterpart)
  *   npf_transpose        W -> W^T for the dgrad chains (no reference counterpart)
@@ -180,15 +182,33 @@ int64_t npf_wgrad_partials_bytes(const npf_wgrad_job_t *jobs, int32_t n_jobs, in
  * scale = 0.01 + 0.99 softplus(raw) (base.py:116); homoskedastic != 0 pools scale over the
  * points of each row-task (base.py:356-362).  If Y != NULL (row-major [n_y_rows][pts][dy],
  * row r uses Y[r % n_y_rows]) also writes sum_logp[n_rows] = sum_t sum_dy log N(y|loc,scale)
- * (losses.py:18-24). */
+ * (losses.py:18-24).  loc == scale == NULL: loss-only launch, only sum_logp is written (nothing of size
+ * [n_rows][pts][dy] is materialised: the multi-sample objectives below only need sum_logp). */
 int npf_gauss_head_fwd(const float *suff, int32_t n_rows, int32_t pts, int32_t dy, int32_t homoskedastic,
                        const float *Y, int32_t n_y_rows, float *loc, float *scale, float *sum_logp,
                        void *stream);
-/* d_suff from (d_loc, d_scale, d_sum_logp): any of the three upstream gradients may be NULL. */
+/* d_suff from (d_loc, d_scale, d_sum_logp): any of the three upstream gradients may be NULL.  loc == scale == NULL
+ * (after a loss-only forward): they are recomputed from suff; d_loc and d_scale must then be NULL. */
 int npf_gauss_head_bwd(const float *suff, const float *loc, const float *scale, int32_t n_rows, int32_t pts,
                        int32_t dy, int32_t homoskedastic, const float *Y, int32_t n_y_rows,
                        const float *d_loc, const float *d_scale, const float *d_sum_logp, float *d_suff,
                        void *stream);
+
+/* ---- Monte-Carlo objectives over the latent samples (npf/losses.py:126-276) ------------ */
+/* log_w: row-major [n_z][n_tasks], the log weight of latent sample k for task b: sum_t log p(y_t | z_k), plus
+ * log q(z_k | C) - log q(z_k | C, T) when the samples come from q(z | C, T).  out[n_tasks]:
+ *   mode 0  mean_k log_w                                  (E_z of ELBOLossLNPF, losses.py:146)
+ *   mode 1  logsumexp_k log_w - log n_z                   (NLLLossLNPF, losses.py:197-200)
+ *   mode 2  SUMO (SUMOLossLNPF, losses.py:262-274): c_k = logsumexp_{j<=k} log_w_j - log(k+1) (k 0-based),
+ *           out = c_{m-1} + sum_{k>=m} inv_weights[k] (c_k - c_{k-1}); inv_weights[n_z] = P(K >= k) of the
+ *           number-of-samples distribution (host), m = the smallest number of samples it draws.
+ * Running logsumexp per task: no [n_z][n_tasks] temporaries (and, with the loss-only Gaussian head above,
+ * nothing of size [n_z][n_tasks][targets][dy]). */
+int npf_mc_objective_fwd(const float *log_w, int32_t n_z, int32_t n_tasks, int32_t mode, const float *inv_weights,
+                         int32_t m, float *out, void *stream);
+/* d_log_w[n_z][n_tasks] from d_out[n_tasks]; workspace: n_z * n_tasks floats (mode 2 only, else may be NULL). */
+int npf_mc_objective_bwd(const float *log_w, int32_t n_z, int32_t n_tasks, int32_t mode, const float *inv_weights,
+                         int32_t m, const float *d_out, float *d_log_w, float *workspace, void *stream);
 
 /* ---- mean aggregation over the points of a task ------------------------------------- */
 /* out[task][F] (row-major) = mean over valid points of PT32 tensor R (np.py:95). */

@@ -8,8 +8,9 @@ from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender
                             merge_flat_input)
 from .chain import set_compute_dtype
 from .datasplit import CntxtTrgtGetter, GetRandomIndcs, GetRangeIndcs, get_all_indcs
+from .evaluate import eval_loglike
 from .losses import CNPFLoss, ELBOLossLNPF, LightTailPareto, NLLLossLNPF, SUMOLossLNPF
-from .neuralproc import (CNP, LNP, AttnCNP, AttnLNP, LatentNeuralProcessFamily, MultivariateNormalDiag,
+from .neuralproc import (CNP, LNP, AttnCNP, AttnLNP, HeadDistribution, LatentNeuralProcessFamily, MultivariateNormalDiag,
                          NeuralProcessFamily)
 
 # north-star aliases: NPFModel / encode / aggregate / decode
@@ -37,5 +38,5 @@ __all__ = [
     "MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender", "SelfAttention", "get_attender",
     "NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP", "NPFModel",
     "CNPFLoss", "ELBOLossLNPF", "NLLLossLNPF", "SUMOLossLNPF", "LightTailPareto", "MultivariateNormalDiag", "encode", "aggregate", "decode",
-    "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs", "set_compute_dtype",
+    "CntxtTrgtGetter", "GetRandomIndcs", "GetRangeIndcs", "get_all_indcs", "set_compute_dtype", "eval_loglike", "HeadDistribution",
 ]

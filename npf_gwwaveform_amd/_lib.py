@@ -69,6 +69,8 @@ SIGNATURES = {
     "npf_wgrad_partials_bytes": (_i64, [C.POINTER(NpfWgradJob), _i32, _i32, _i32]),
     "npf_gauss_head_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p]),
     "npf_gauss_head_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    "npf_mc_objective_fwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p, _p]),
+    "npf_mc_objective_bwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p]),
     "npf_mean_agg_fwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "npf_mean_agg_bwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
     "npf_pack_pt": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),

@@ -25,15 +25,14 @@ from . import _lib as L
 __all__ = ["get_all_indcs", "GetRangeIndcs", "GetRandomIndcs", "CntxtTrgtGetter"]
 
 
-def _ratio_to_int(percentage, max_val):
-    """npf/utils/helpers.py:99-108."""
-    if 1 <= percentage <= max_val:
-        out = percentage
-    elif 0 <= percentage < 1:
-        out = percentage * max_val
-    else:
-        raise ValueError("percentage={} outside of [0,{}].".format(percentage, max_val))
-    return int(out)
+def _point_count(spec, n_points: int) -> int:
+    """A number of points given either as a count (1 <= spec <= n_points) or as a fraction of ``n_points``
+    (0 <= spec < 1), the convention of the reference's getters (npf/utils/helpers.py:99-108)."""
+    if 0 <= spec < 1:
+        return int(spec * n_points)
+    if 1 <= spec <= n_points:
+        return int(spec)
+    raise ValueError("percentage={} outside of [0,{}].".format(spec, n_points))
 
 
 def get_all_indcs(batch_size, n_possible_points, device=None):
@@ -72,7 +71,7 @@ class GetRandomIndcs:
 
             n = int(betabinom(n_possible_points, self.a, self.b).rvs())
         else:
-            n = random.randint(_ratio_to_int(self.a, n_possible_points), _ratio_to_int(self.b, n_possible_points))
+            n = random.randint(_point_count(self.a, n_possible_points), _point_count(self.b, n_possible_points))
         if self.is_ensure_one and n < 1:
             n = 1
         return n
@@ -94,46 +93,57 @@ class GetRandomIndcs:
 
 
 class CntxtTrgtGetter:
-    """Split (X, y) into context and target points by indices (datasplit.py:148-255)."""
+    """Split (X, y) into context and target points (datasplit.py:148-255): ``getter(X, y)`` ->
+    ``X_cntxt, Y_cntxt, X_trgt, Y_trgt``.  Same constructor arguments, call signature and overridable hooks
+    (``preprocess_context``, ``add_cntxts_to_trgts``, ``getter_inputs``, ``select``) as the reference; the work is
+    two steps: :meth:`indices` decides which points go where (device-side draws unless the caller supplies them),
+    :meth:`select` moves them (one gather launch per side)."""
 
     def __init__(self, contexts_getter=GetRandomIndcs(), targets_getter=get_all_indcs, is_add_cntxts_to_trgts=False):
         self.contexts_getter = contexts_getter
         self.targets_getter = targets_getter
         self.is_add_cntxts_to_trgts = is_add_cntxts_to_trgts
 
-    def __call__(self, X, y=None, context_indcs=None, target_indcs=None, is_return_indcs=False):
+    def indices(self, X, context_indcs=None, target_indcs=None):
+        """(context indices, target indices, were any supplied by the caller) for the batch ``X``."""
         batch_size, num_points = self.getter_inputs(X)
-        given = context_indcs is not None or target_indcs is not None  # caller-supplied indices get range-checked
-        if context_indcs is None:
-            context_indcs = self._draw(self.contexts_getter, batch_size, num_points, X.device)
-        if target_indcs is None:
-            target_indcs = self._draw(self.targets_getter, batch_size, num_points, X.device)
+        supplied = not (context_indcs is None and target_indcs is None)
+        drawn = []
+        for given, getter in ((context_indcs, self.contexts_getter), (target_indcs, self.targets_getter)):
+            if given is not None:
+                drawn.append(given)
+                continue
+            try:
+                drawn.append(getter(batch_size, num_points, device=X.device))
+            except TypeError:  # a reference-style getter without the device argument
+                drawn.append(getter(batch_size, num_points))
+        ctx, trg = drawn
         if self.is_add_cntxts_to_trgts:
-            target_indcs = self.add_cntxts_to_trgts(num_points, target_indcs, context_indcs)
-        X_pre_cntxt = self.preprocess_context(X)
+            trg = self.add_cntxts_to_trgts(num_points, trg, ctx)
+        return ctx, trg, supplied
+
+    def __call__(self, X, y=None, context_indcs=None, target_indcs=None, is_return_indcs=False):
+        ctx, trg, supplied = self.indices(X, context_indcs, target_indcs)
+        X_for_context = self.preprocess_context(X)
         if is_return_indcs:
-            return context_indcs, X_pre_cntxt, target_indcs, X
-        X_cntxt, Y_cntxt = self.select(X_pre_cntxt, y, context_indcs, validate=given)
-        X_trgt, Y_trgt = self.select(X, y, target_indcs, validate=given)
-        return X_cntxt, Y_cntxt, X_trgt, Y_trgt
+            return ctx, X_for_context, trg, X
+        # caller-supplied indices are range-checked (one host sync); the getters' own draws are in range by construction
+        return (*self.select(X_for_context, y, ctx, validate=supplied), *self.select(X, y, trg, validate=supplied))
 
-    @staticmethod
-    def _draw(getter, batch_size, num_points, device):
-        try:
-            return getter(batch_size, num_points, device=device)
-        except TypeError:  # a reference-style getter without the device argument
-            return getter(batch_size, num_points)
-
+    # ---- hooks of the reference ---------------------------------------------------------------------------------
     def preprocess_context(self, X):
+        """What the context side sees of X (identity; the reference's subclasses mask or crop here)."""
         return X
 
     def add_cntxts_to_trgts(self, num_points, target_indcs, context_indcs):
-        target_indcs = torch.cat([torch.as_tensor(target_indcs), torch.as_tensor(context_indcs).to(target_indcs.device)], dim=-1)
-        return target_indcs[:, :num_points]
+        """Targets followed by the context points, cut to ``num_points`` columns (datasplit.py:225-232)."""
+        trg = torch.as_tensor(target_indcs)
+        both = torch.cat([trg, torch.as_tensor(context_indcs).to(trg.device)], dim=-1)
+        return both[:, :num_points]
 
     def getter_inputs(self, X):
-        batch_size, num_points, x_dim = X.shape
-        return batch_size, num_points
+        """(batch size, number of points) handed to the index getters."""
+        return X.shape[0], X.shape[1]
 
     def select(self, X, y, indcs, validate=True):
         """``torch.gather`` of X and y along the points with the same indices (datasplit.py:246-255):

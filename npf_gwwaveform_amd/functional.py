@@ -95,12 +95,14 @@ def mean_agg(pt: torch.Tensor, pts: int, F: int) -> torch.Tensor:
 # ---- Gaussian head --------------------------------------------------------------------
 class _GaussHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, suff, Y, dy, homosk):
+    def forward(ctx, suff, Y, dy, homosk, want_dist):
         n_rows, pts, two_dy = suff.shape
         assert two_dy == 2 * dy
         suff = suff.contiguous()
-        loc = torch.empty((n_rows, pts, dy), dtype=torch.float32, device=suff.device)
-        scale = torch.empty_like(loc)
+        loc = scale = None
+        if want_dist:
+            loc = torch.empty((n_rows, pts, dy), dtype=torch.float32, device=suff.device)
+            scale = torch.empty_like(loc)
         slp = None
         n_y = 0
         if Y is not None:
@@ -108,14 +110,18 @@ class _GaussHeadFn(torch.autograd.Function):
             n_y = Y.shape[0]
             assert Y.shape[1:] == (pts, dy) and n_rows % n_y == 0
             slp = torch.empty((n_rows,), dtype=torch.float32, device=suff.device)
+        elif not want_dist:
+            raise ValueError("a loss-only head launch needs the targets")
         L.check(L.load().npf_gauss_head_fwd(L.ptr(suff), n_rows, pts, dy, int(homosk), L.ptr(Y), n_y, L.ptr(loc),
                                             L.ptr(scale), L.ptr(slp), L.stream_ptr()), "npf_gauss_head_fwd")
         ctx.save_for_backward(suff, loc, scale, Y)
         ctx.cfg = (dy, homosk)
-        if slp is None:
-            slp = torch.zeros((n_rows,), dtype=torch.float32, device=suff.device)
-            ctx.mark_non_differentiable(slp)
-        return loc, scale, slp
+        empty = suff.new_zeros((0,))
+        outs = [loc if want_dist else empty, scale if want_dist else empty, slp if slp is not None else suff.new_zeros((n_rows,))]
+        nd = ([] if want_dist else [outs[0], outs[1]]) + ([] if slp is not None else [outs[2]])
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, d_loc, d_scale, d_slp):
@@ -124,18 +130,55 @@ class _GaussHeadFn(torch.autograd.Function):
         n_rows, pts, _ = suff.shape
         d_suff = torch.empty_like(suff)
         c = lambda t: t.contiguous() if t is not None else None  # noqa: E731
+        if loc is None:
+            d_loc = d_scale = None
         L.check(L.load().npf_gauss_head_bwd(L.ptr(suff), L.ptr(loc), L.ptr(scale), n_rows, pts, dy, int(homosk),
                                             L.ptr(Y), Y.shape[0] if Y is not None else 0, L.ptr(c(d_loc)),
                                             L.ptr(c(d_scale)), L.ptr(c(d_slp)) if Y is not None else None,
                                             L.ptr(d_suff), L.stream_ptr()), "npf_gauss_head_bwd")
-        return d_suff, None, None, None
+        return d_suff, None, None, None, None
 
 
-def gauss_head(suff: torch.Tensor, Y: Optional[torch.Tensor], dy: int, homoskedastic: bool):
+def gauss_head(suff: torch.Tensor, Y: Optional[torch.Tensor], dy: int, homoskedastic: bool, want_dist: bool = True):
     """(loc, scale, sum_log_prob) from the raw decoder output ``suff`` [rows, pts, 2*dy]
     (npf/neuralproc/base.py:350-365; losses.py:18-24).  ``sum_log_prob`` [rows] is the
-    log-likelihood of ``Y`` [rows or B, pts, dy] summed over targets and y-dims."""
-    return _GaussHeadFn.apply(suff, Y, dy, homoskedastic)
+    log-likelihood of ``Y`` [rows or B, pts, dy] summed over targets and y-dims.  ``want_dist=False``: a
+    loss-only launch -- loc and scale come back empty and nothing of size [rows, pts, dy] is written."""
+    return _GaussHeadFn.apply(suff, Y, dy, homoskedastic, want_dist)
+
+
+# ---- Monte-Carlo objectives over the latent samples -------------------------------------
+MC_MEAN, MC_LOGMEANEXP, MC_SUMO = 0, 1, 2
+
+
+class _McObjectiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_w, mode, inv_w, m):
+        n_z, B = log_w.shape
+        log_w = log_w.contiguous()
+        out = torch.empty((B,), dtype=torch.float32, device=log_w.device)
+        L.check(L.load().npf_mc_objective_fwd(L.ptr(log_w), n_z, B, mode, L.ptr(inv_w), m, L.ptr(out), L.stream_ptr()),
+                "npf_mc_objective_fwd")
+        ctx.save_for_backward(log_w, inv_w)
+        ctx.cfg = (mode, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        log_w, inv_w = ctx.saved_tensors
+        mode, m = ctx.cfg
+        n_z, B = log_w.shape
+        d = torch.empty_like(log_w)
+        ws = torch.empty_like(log_w) if mode == MC_SUMO else None
+        L.check(L.load().npf_mc_objective_bwd(L.ptr(log_w), n_z, B, mode, L.ptr(inv_w), m, L.ptr(d_out.contiguous()), L.ptr(d),
+                                              L.ptr(ws), L.stream_ptr()), "npf_mc_objective_bwd")
+        return d, None, None, None
+
+
+def mc_objective(log_w: torch.Tensor, mode: int, inv_weights: Optional[torch.Tensor] = None, m: int = 0) -> torch.Tensor:
+    """Per-task estimate [B] from the log weights ``log_w`` [n_z, B] of the latent samples
+    (``npf_mc_objective_fwd``): their mean, log-mean-exp, or the SUMO estimate."""
+    return _McObjectiveFn.apply(log_w, mode, inv_weights, m)
 
 
 class _HeadsFn(torch.autograd.Function):

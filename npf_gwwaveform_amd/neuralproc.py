@@ -31,7 +31,7 @@ from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender
 from .chain import Chain, PTensor, pad32
 
 __all__ = ["NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP",
-           "MultivariateNormalDiag"]
+           "MultivariateNormalDiag", "HeadDistribution"]
 
 
 def MultivariateNormalDiag(loc, scale_diag):
@@ -39,6 +39,38 @@ def MultivariateNormalDiag(loc, scale_diag):
     if loc.dim() < 1:
         raise ValueError("loc must be at least one-dimensional.")
     return Independent(Normal(loc, scale_diag, validate_args=False), 1)
+
+
+class HeadDistribution(Independent):
+    """``MultivariateNormalDiag(loc, scale)`` of the decoder's raw output (base.py:350-367) -- an
+    ``Independent(Normal(loc, scale), 1)`` with batch shape [n_z, B, T] and event shape [y_dim] -- evaluated lazily:
+    ``loc`` / ``scale`` are only materialised ([n_z, B, T, y_dim] each, one ``npf_gauss_head_fwd`` launch) when
+    ``base_dist`` (or anything that needs it: ``mean``, ``log_prob``, ``sample`` ...) is first touched.  The
+    training and evaluation objectives never do: :meth:`sum_log_prob` is a loss-only launch that writes one float
+    per (z-sample, task)."""
+
+    def __init__(self, suff, y_dim, homoskedastic, n_z, B, T):
+        torch.distributions.Distribution.__init__(self, torch.Size((n_z, B, T)), torch.Size((y_dim,)), validate_args=False)
+        self.reinterpreted_batch_ndims = 1
+        self._suff, self._y_dim, self._homosk = suff, y_dim, homoskedastic
+        self._base = None
+        self._slp = None  # (targets, [n_z, B] sum of log-probabilities) of the last sum_log_prob call
+
+    @property
+    def base_dist(self):
+        if self._base is None:
+            n_z, B, T = self.batch_shape
+            loc, scale, _ = FN.gauss_head(self._suff, None, self._y_dim, self._homosk)
+            self._base = Normal(loc.view(n_z, B, T, self._y_dim), scale.view(n_z, B, T, self._y_dim), validate_args=False)
+        return self._base
+
+    def sum_log_prob(self, Y_trgt):
+        """sum_t log p(y_t) -> [n_z, B] (npf/losses.py:18-24), fused with the head in one loss-only launch."""
+        if self._slp is None or self._slp[0] is not Y_trgt:
+            n_z, B, _ = self.batch_shape
+            _, _, slp = FN.gauss_head(self._suff, Y_trgt.contiguous(), self._y_dim, self._homosk, want_dist=False)
+            self._slp = (Y_trgt, slp.view(n_z, B))
+        return self._slp[1]
 
 
 def _q_z_scale(z_scale):
@@ -149,15 +181,7 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         return self.xy_encoder.run_pt(ch, X_enc.t, X_enc.n_tasks, X_enc.pts, with_tr=self._attentive)
 
     def _head(self, suff, Y_trgt, B, T):
-        n_rows = suff.shape[0]
-        loc, scale, slp = FN.gauss_head(suff, Y_trgt, self.y_dim, not self.is_heteroskedastic)
-        n_z = n_rows // B
-        p = self.PredictiveDistribution(loc.view(n_z, B, T, self.y_dim), scale.view(n_z, B, T, self.y_dim))
-        if Y_trgt is not None:
-            # fused sum_t log p(y_t) of the head kernel, picked up by npf_gwwaveform_amd.losses
-            p._npf_sum_log_prob = (Y_trgt, slp.view(n_z, B))
-        p._npf_suff = (suff, self.y_dim, not self.is_heteroskedastic)
-        return p
+        return HeadDistribution(suff, self.y_dim, not self.is_heteroskedastic, suff.shape[0] // B, B, T)
 
     def _decode_taskvec(self, Xt_pt, vec, B, T, n_rows):
         """decoder(X_trgt_enc, R_trgt) when R_trgt is one vector per (z-sample, task)

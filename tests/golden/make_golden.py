@@ -287,6 +287,34 @@ def run_selfattn_case():
     print("g11_attncnp_selfattn: loss", float(loss), "n_params", sum(p.numel() for p in model.parameters()))
 
 
+def run_eval_case():
+    """G12: the evaluation protocol of utils/evaluate.py:9-28 on the reference's modules --
+    evaluation mode, ``reduction=None``, 32 latent samples at test time (``n_z_samples_test=32``), the per-task
+    log-likelihood (minus the criterion) of two batches, concatenated.  Training criterion ELBO (so that the
+    evaluation really exercises losses.py:65-69: NLL with the importance weights dropped) and SUMO."""
+    res = {}
+    for tag, case, crit_cls in (("attnlnp", specs.EVAL_CASES["attnlnp"], npf.ELBOLossLNPF),
+                                ("lnp", specs.EVAL_CASES["lnp"], npf.SUMOLossLNPF),
+                                ("cnp", specs.EVAL_CASES["cnp"], npf.CNPFLoss)):
+        model = build_reference(case)
+        model.load_state_dict(specs.make_params(case), strict=True)
+        model.eval()
+        crit = crit_cls()
+        crit.reduction = None  # (as eval_loglike does; the reference's SUMOLossLNPF.__init__ drops its keyword arguments)
+        crit.eval()
+        ll = []
+        for i in range(2):
+            inp = specs.make_inputs(case, seed=5000 + i)
+            if "eps" in inp:
+                _EpsIndependent.eps = inp["eps"]
+            with torch.no_grad():
+                out = model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+                ll.append(-crit(out, inp["Y_trgt"]))
+        res[f"{tag}_loglike"] = torch.cat(ll, 0).numpy()
+        print(f"g12 {tag}: log-likelihoods", res[f"{tag}_loglike"])
+    np.savez_compressed(os.path.join(HERE, "g12_eval_loglike.npz"), **res)
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
     if only:  # e.g. `make_golden.py g8_ g9` regenerates the matching cases only
@@ -297,6 +325,8 @@ if __name__ == "__main__":
             run_pretrained_attn()
         if any(o.startswith("g11") for o in only):
             run_selfattn_case()
+        if any(o.startswith("g12") for o in only):
+            run_eval_case()
         sys.exit(0)
     small_full = {"g1_cnp_c1", "g2_lnp_both_c1", "g2_lnp_latent_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64",
                   "g4s_attnlnp_r64_noqzcct"}
@@ -309,3 +339,4 @@ if __name__ == "__main__":
     run_pretrained()
     run_pretrained_attn()
     run_selfattn_case()
+    run_eval_case()

@@ -61,6 +61,13 @@ CASES = {
                                    attention="transformer", is_q_zCct=True, n_z=2),
 }
 
+# G12: evaluation protocol (utils/evaluate.py:9-28): 32 latent samples at test time, per-task log-likelihoods
+EVAL_CASES = {
+    "attnlnp": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=5, C=21, T=50, is_q_zCct=True, n_z=32),
+    "lnp": dict(kind="LNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=4, C=10, T=33, encoded_path="latent", is_q_zCct=True, n_z=32),
+    "cnp": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=9, T=20),
+}
+
 # G5: decode-only, config-5 decoder (r=512, L=4) at reduced batch
 DECODE_CASE = dict(r=512, L_dec=4, dx=1, dy=2, B=2, T=4096)
 

@@ -162,3 +162,41 @@ def test_oracle_pretrained_attn_checkpoints():
             got, ref = out[key].detach().numpy(), g[f"{tag}_{key}"]
             assert got.shape == ref.shape
             np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(), err_msg=f"{tag} {key}")
+
+
+def test_oracle_eval_loglike_protocol_g12():
+    """G12: the reference's evaluation protocol (utils/evaluate.py:9-28: evaluation mode, reduction None, 32 latent
+    samples at test time, NLL without importance weights, sign flipped) restated with the oracle's forward + nll_loss."""
+    g = specs.load_golden("g12_eval_loglike")
+    for tag, case in specs.EVAL_CASES.items():
+        cfg = specs.cfg_of(case)
+        params = specs.make_params(case)
+        ll = []
+        for i in range(2):
+            inp = specs.make_inputs(case, seed=5000 + i)
+            with torch.no_grad():
+                out = O.forward(cfg, params, inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"], eps=inp.get("eps"),
+                                n_z=case.get("n_z", 1), training=False)
+                out = dict(out, q_zCct=None)  # is_force_mle_eval (losses.py:65-69)
+                ll.append(-O.nll_loss(out, inp["Y_trgt"], reduction=None))
+        np.testing.assert_allclose(torch.cat(ll).numpy(), g[f"{tag}_loglike"], rtol=2e-6, err_msg=tag)
+
+
+def test_oracle_bf16_mode_backward_formulas():
+    """The hand-written backward of the bf16 emulation (``_LinearBf16``): with operands and upstream gradient that are
+    exactly representable in bf16 the rounding is the identity, and the result must equal plain autograd."""
+    g = torch.Generator().manual_seed(0)
+    r16 = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x, W, b = r16(torch.randn(7, 12, generator=g)), r16(torch.randn(5, 12, generator=g)), torch.randn(5, generator=g)
+    dy = r16(torch.randn(7, 5, generator=g))
+    ref_in = [t.clone().requires_grad_(True) for t in (x, W, b)]
+    torch.nn.functional.linear(*ref_in).backward(dy)
+    got_in = [t.clone().requires_grad_(True) for t in (x, W, b)]
+    with O.matmul_mode("bf16"):
+        O.linear(*got_in).backward(dy)
+    for a, c in zip(got_in, ref_in):
+        torch.testing.assert_close(a.grad, c.grad, rtol=1e-6, atol=1e-6)
+    # and it really rounds: an input that is not representable changes the product
+    with O.matmul_mode("bf16"):
+        y16 = O.linear(x + 1e-3, W, b)
+    assert not torch.allclose(y16, torch.nn.functional.linear(x + 1e-3, W, b), rtol=0, atol=1e-6)
