@@ -54,8 +54,8 @@ extern "C" {
 #define NPF_ELAUNCH (-2)  /* hipLaunch failed (hipGetLastError != 0)    */
 
 #define NPF_MAX_OPS 40
-#define NPF_MAX_FEATURES 512 /* widest activation a chain keeps in registers (programs that stay
-                                <= 256 wide run the 2-workgroups-per-CU variant of the kernel) */
+#define NPF_MAX_FEATURES 512 /* widest activation a chain keeps in registers, forward and backward (programs that
+                                stay <= 256 wide run the 2-workgroups-per-CU variants of the kernel) */
 
 /* ---- chain programs ------------------------------------------------------------- */
 enum npf_opcode {
@@ -163,6 +163,13 @@ typedef struct npf_wgrad_job {
   int32_t per_task;
   int32_t accumulate; /* bit 0: 0 = overwrite dW/db, 1 = add to them; bit 1 (NPF_WGRAD_BF16): round the
                          operands to bf16 at the MFMA input (bf16 compute mode; all jobs of a launch alike) */
+  /* A job covers at most 256 x 256 of dW.  Wider layers (up to NPF_MAX_FEATURES = 512 features per side, the
+   * reference's MLPs have no limit: npf/architectures/mlp.py:44-93) are run as several jobs on blocks of the
+   * operands: dZ / A then point at the block's first feature inside the (wider) tensor and ldz / lda give the
+   * features per tile of that tensor (0 = the job's own roundup(N, 32) / roundup(K, 32)); ldo likewise for the
+   * PT32 output of a per-task job whose K is a block of a wider tensor. */
+  int32_t ldz, lda, ldo;
+  int32_t reserved;
 } npf_wgrad_job_t;
 #define NPF_WGRAD_ACCUMULATE 1
 #define NPF_WGRAD_BF16 2

@@ -15,8 +15,9 @@ import torch
 from . import _build
 
 NPF_MAX_OPS = 40
-NPF_MAX_FEATURES = 512        # widest layer side of a chain (inference)
-NPF_MAX_TRAIN_FEATURES = 256  # widest layer side with a backward pass (npf_wgrad_run)
+NPF_MAX_FEATURES = 512        # widest layer side of a chain, forward and backward
+NPF_WGRAD_BLOCK = 256         # widest block of dW one wgrad job covers (wider layers are split into block jobs)
+NPF_MAX_FUSED_ROW = 256       # features of one fused attention score row / LayerNorm row / bf16 layer (16-block instances)
 
 # opcodes (enum npf_opcode)
 OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFTMAX, OP_ADD_PT, OP_MASK_POS, \
@@ -47,6 +48,7 @@ class NpfWgradJob(C.Structure):
     _fields_ = [
         ("dZ", C.c_void_p), ("A", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("ldw", C.c_int64),
         ("N", C.c_int32), ("K", C.c_int32), ("per_task", C.c_int32), ("accumulate", C.c_int32),
+        ("ldz", C.c_int32), ("lda", C.c_int32), ("ldo", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -59,7 +61,7 @@ class NpfWprepJob(C.Structure):
 
 
 NPF_MAX_WPREP_JOBS = 32
-assert C.sizeof(NpfOp) == 72 and C.sizeof(NpfProgram) == 32 + 72 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 56 and C.sizeof(NpfWprepJob) == 32
+assert C.sizeof(NpfOp) == 72 and C.sizeof(NpfProgram) == 32 + 72 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 72 and C.sizeof(NpfWprepJob) == 32
 
 # name -> (restype, argtypes); must list every symbol declared in include/npf_hip.h
 _i32, _i64, _p = C.c_int32, C.c_int64, C.c_void_p

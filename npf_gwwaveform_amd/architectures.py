@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as FN
-from ._lib import NPF_MAX_TRAIN_FEATURES
+from ._lib import NPF_MAX_FUSED_ROW
 from .chain import Chain, PTensor
 
 __all__ = ["MLP", "MergeFlatInputs", "merge_flat_input", "DotAttender", "MultiheadAttender", "TransformerAttender",
@@ -106,7 +106,7 @@ class MLP(nn.Module):
             return x.new_zeros(*lead, self.output_size)
         ch = Chain(1, rows, x.device)
         ch.input_pt(FN.pack_pt(x.reshape(1, rows, n_in)), n_in)
-        if self.output_size <= NPF_MAX_TRAIN_FEATURES:
+        if self.output_size <= NPF_MAX_FUSED_ROW:
             self.append_to(ch).output_pt()
             (y,) = ch.run()
             return FN.unpack_pt(y, rows, self.output_size).reshape(*lead, self.output_size)
@@ -116,8 +116,8 @@ class MLP(nn.Module):
             ch.linear(lin.weight, lin.bias, relu=True)
         (h,) = ch.output_pt().run()
         outs = []
-        for lo in range(0, self.output_size, NPF_MAX_TRAIN_FEATURES):
-            hi = min(lo + NPF_MAX_TRAIN_FEATURES, self.output_size)
+        for lo in range(0, self.output_size, NPF_MAX_FUSED_ROW):
+            hi = min(lo + NPF_MAX_FUSED_ROW, self.output_size)
             c2 = Chain(1, rows, x.device)
             c2.input_pt(h, self.hidden_size)
             c2.linear(self.out.weight[lo:hi], self.out.bias[lo:hi] if self.out.bias is not None else None).output_pt()
@@ -240,7 +240,7 @@ class DotAttender(nn.Module):
 
     def fits_fused(self, n_keys: int) -> bool:
         """Can ``append_to`` keep a whole score row in registers (else: ``attend_pt``)."""
-        return n_keys <= NPF_MAX_TRAIN_FEATURES
+        return n_keys <= NPF_MAX_FUSED_ROW
 
     def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
         """PT32 in, PT32 out, any number of keys (fused chain up to 256 keys, blocked softmax of

@@ -163,9 +163,9 @@ def long_scaledot_attention(q_pt: torch.Tensor, k_pt: torch.Tensor, v_pt: torch.
     """``softmax(scale * q K^T) V`` on PT32 tensors (queries [B, T, r], keys / values [B, C, r]) for any
     number of keys; returns the PT32 context vectors [B, T, r].  ``k_tr`` / ``v_tr``: optional
     feature-major copies of keys / values (``Chain.store_tr``)."""
-    if r > L.NPF_MAX_TRAIN_FEATURES:
+    if r > L.NPF_MAX_FUSED_ROW:
         raise NotImplementedError(f"attention over {r}-wide keys: the HIP path keeps at most "
-                                  f"{L.NPF_MAX_TRAIN_FEATURES} features per point in training")
+                                  f"{L.NPF_MAX_FUSED_ROW} features per point in training")
     if k_pt.shape[1] != tiles_of(n_keys) or pad32(r) // 4 != k_pt.shape[2]:
         raise ValueError("keys tensor does not match (n_keys, r)")
     return _LongScaledDot.apply(q_pt, k_pt, v_pt, n_keys, n_queries, r, float(scale), k_tr, v_tr)

@@ -325,8 +325,37 @@ def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
         _run_wgrad(jobs, n_tasks, pts, device)
 
 
+def _block_jobs(jobs: Sequence[dict]) -> List[dict]:
+    """One wgrad job covers at most 256 x 256 of dW (``NPF_WGRAD_BLOCK``): a wider layer becomes one job per block,
+    each pointing at its block of features inside the (wider) operand tensors (``ldz`` / ``lda`` / ``ldo`` = features
+    per tile of those tensors).  Blocks are multiples of 256 features, i.e. whole rows of a PT tile."""
+    Bk = L.NPF_WGRAD_BLOCK
+    out = []
+    for jb in jobs:
+        N, K = jb["N"], jb["K"]
+        if N <= Bk and K <= Bk:
+            out.append(jb)
+            continue
+        if jb.get("per_task") and N > Bk:
+            raise NotImplementedError("per-task weight gradients (attention keys / values) over more than 256 points")
+        dZ, A = jb["dZ"], jb["A"]
+        Fz, Fa = pad32(N), pad32(K)
+        ldw = jb.get("ldw") or K
+        for n0 in range(0, N, Bk):
+            for k0 in range(0, K, Bk):
+                blk = dict(jb, N=min(Bk, N - n0), K=min(Bk, K - k0), ldz=Fz, lda=Fa,
+                           dZ_off=n0 * 32, A_off=k0 * 32)  # element offsets of the block inside every tile
+                if jb.get("per_task"):
+                    blk.update(dW_off=k0 * 32, ldo=Fa)  # PT32 output: the block of features k0.. of every row tile
+                else:
+                    blk.update(dW_off=n0 * ldw + k0, ldw=ldw, db=jb.get("db") if k0 == 0 else None, db_off=n0)
+                out.append(blk)
+    return out
+
+
 def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
     lib = L.load()
+    jobs = _block_jobs(jobs)
     for i0 in range(0, len(jobs), L.NPF_MAX_WGRAD_JOBS):
         chunk = jobs[i0:i0 + L.NPF_MAX_WGRAD_JOBS]
         arr = (L.NpfWgradJob * len(chunk))()
@@ -334,10 +363,11 @@ def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
             z16, a16 = jb["dZ"].dtype == torch.bfloat16, jb["A"].dtype == torch.bfloat16  # PT16 operands (bf16 mode)
             if (z16 or a16) and COMPUTE_DTYPE != "bf16":
                 raise RuntimeError("PT16 operands exist in the bf16 compute mode only")
-            arr[j].dZ = jb["dZ"].data_ptr() if z16 else L.ptr(jb["dZ"])
-            arr[j].A = jb["A"].data_ptr() if a16 else L.ptr(jb["A"])
-            arr[j].dW = L.ptr(jb["dW"])
-            arr[j].db = L.ptr(jb.get("db"))
+            arr[j].dZ = (jb["dZ"].data_ptr() if z16 else L.ptr(jb["dZ"])) + jb.get("dZ_off", 0) * jb["dZ"].element_size()
+            arr[j].A = (jb["A"].data_ptr() if a16 else L.ptr(jb["A"])) + jb.get("A_off", 0) * jb["A"].element_size()
+            arr[j].dW = L.ptr(jb["dW"]) + 4 * jb.get("dW_off", 0)
+            arr[j].db = (L.ptr(jb["db"]) + 4 * jb.get("db_off", 0)) if jb.get("db") is not None else None
+            arr[j].ldz, arr[j].lda, arr[j].ldo = jb.get("ldz", 0), jb.get("lda", 0), jb.get("ldo", 0)
             arr[j].ldw = jb.get("ldw") or jb["K"]
             arr[j].N, arr[j].K = jb["N"], jb["K"]
             arr[j].per_task = int(jb.get("per_task", False))
@@ -486,7 +516,7 @@ class Chain:
 
     def layernorm(self, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> "Chain":
         """cur <- LayerNorm(cur) over the features (nn.LayerNorm with affine parameters)."""
-        if self.F > L.NPF_MAX_TRAIN_FEATURES or weight.shape != (self.F,) or bias.shape != (self.F,):
+        if self.F > L.NPF_MAX_FUSED_ROW or weight.shape != (self.F,) or bias.shape != (self.F,):
             raise ValueError(f"LayerNorm over {self.F} features with parameters {tuple(weight.shape)}")
         self.steps.append(_Step("layernorm", {"g": self._t(weight), "b": self._t(bias)}, {"F": self.F, "eps": float(eps)}))
         return self
@@ -506,9 +536,9 @@ class Chain:
         lets the backward pass stream K^T by LDS-DMA."""
         if not self.wg_per_task:
             raise ValueError("attention needs wg_per_task=True")
-        if n_keys > L.NPF_MAX_TRAIN_FEATURES:
+        if n_keys > L.NPF_MAX_FUSED_ROW:
             raise NotImplementedError(
-                f"a fused score row holds at most {L.NPF_MAX_TRAIN_FEATURES} context points; longer contexts go "
+                f"a fused score row holds at most {L.NPF_MAX_FUSED_ROW} context points; longer contexts go "
                 "through DotAttender.attend_pt (attention_long.py)")
         self.steps.append(_Step("attn_scores", {"k": self._t(keys_pt)}, {"C": n_keys, "r": self.F, "tr": keys_tr,
                                                                           "img": keys_img}))
@@ -561,7 +591,8 @@ class Chain:
         launch and travel with the result."""
         F = self.F
         self.output_pt()
-        imgs = as_weights and COMPUTE_DTYPE == "bf16"
+        widest = max([max(st.a["N"], st.a["K"]) for st in self.steps if st.kind == "linear"], default=0)
+        imgs = as_weights and COMPUTE_DTYPE == "bf16" and max(widest, F) <= L.NPF_MAX_FUSED_ROW  # (a bf16 chain: <= 256 wide)
         if as_weights:
             self.store_tr()
         if imgs:
@@ -578,12 +609,6 @@ class _ChainFn(torch.autograd.Function):
         if not chain.grad_enabled:
             needs_grad = [False] * len(needs_grad)
         train = any(needs_grad)  # (grad mode is always off inside Function.forward)
-        if train:
-            for st in chain.steps:
-                if st.kind == "linear" and max(st.a["N"], st.a["K"]) > L.NPF_MAX_TRAIN_FEATURES:
-                    raise NotImplementedError(
-                        f"training through a {st.a['K']}->{st.a['N']} layer: the backward kernels handle at most "
-                        f"{L.NPF_MAX_TRAIN_FEATURES} features per side (inference works up to {L.NPF_MAX_FEATURES})")
         prog = Program(chain.n_tasks, chain.pts, chain.wg_per_task)
         dev = chain.device
         T = [t.detach() if t is not None else None for t in chain.tensors]

@@ -186,9 +186,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   // points] 16-byte chunks = half the bytes and half the rows of the fp32 tile; same 512-byte rows, same swizzle.
   const bool z16 = BF16 && (job.accumulate & NPF_WGRAD_DZ16) != 0, a16 = BF16 && (job.accumulate & NPF_WGRAD_A16) != 0;
   const int zsh = z16 ? 4 : 3, ash = a16 ? 4 : 3;  // pieces per tile = F >> sh, tile bytes = F << (10 - sh)
+  // features per tile of the tensors the operands live in (a job on a block of <= 256 features of a wider tensor --
+  // NPF_MAX_TRAIN_FEATURES = 512 is split into such jobs -- points at the block's first feature row and strides over
+  // the whole tile)
+  const int Zf = job.ldz > 0 ? job.ldz : Np, Af = job.lda > 0 ? job.lda : Kp;
   auto tile_dma = [&](long t, float* buf) {
-    const char* zsrc = dz_base + (((size_t)t * Np) << (10 - zsh));
-    const char* asrc = a_base + (((size_t)t * Kp) << (10 - ash));
+    const char* zsrc = dz_base + (((size_t)t * Zf) << (10 - zsh));
+    const char* asrc = a_base + (((size_t)t * Af) << (10 - ash));
     for (int q = wave; q < (Np >> zsh); q += kWgWaves)
       wg_dma16((const float*)(zsrc + (size_t)q * 1024 + (size_t)dma_lane), buf + q * 256);
     for (int q = wave; q < (Kp >> ash); q += kWgWaves)
@@ -290,15 +294,16 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 #pragma unroll
     for (int n = 0; n < 4; ++n) col[n] = wg_feature(a16, cg, i, n);
     if (job.per_task) {
-      // PT32 tensor, points = row index (n of dW), features = column index (k)
-      float* out = job.dW + (size_t)split * ((Np >> 5) * Kp * 32);
+      // PT32 tensor, points = row index (n of dW), features = column index (k); ldo: features per tile of that tensor
+      const int Ko = job.ldo > 0 ? job.ldo : Kp;
+      float* out = job.dW + (size_t)split * ((size_t)(Np >> 5) * Ko * 32);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = wg_feature(z16, rg, 4 * g + e, m);
           if (row >= Np) continue;
-          float* rbase = out + (size_t)(row >> 5) * (Kp >> 2) * 128 + (row & 31) * 4;
+          float* rbase = out + (size_t)(row >> 5) * (Ko >> 2) * 128 + (row & 31) * 4;
           if (!a16) {
             if (col[0] < Kp) {
               f32x4 v;
@@ -411,6 +416,10 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
     if ((((uintptr_t)b.dZ) | ((uintptr_t)b.A)) & 15) return NPF_EINVAL;
     if (b.per_task && (((uintptr_t)b.dW) & 15)) return NPF_EINVAL;
     if (!b.per_task && b.ldw < b.K) return NPF_EINVAL;
+    if (b.ldz < 0 || b.lda < 0 || b.ldo < 0 || (b.ldz & 31) || (b.lda & 31) || (b.ldo & 31)) return NPF_EINVAL;
+    if ((b.ldz && b.ldz < npf::round_up(b.N, 32)) || (b.lda && b.lda < npf::round_up(b.K, 32)) ||
+        (b.ldo && b.ldo < npf::round_up(b.K, 32)))
+      return NPF_EINVAL;
     n_shared += b.per_task ? 0 : 1;
   }
   // workgroups per shared-weight job, proportional to its per-tile time: with the wave mapping

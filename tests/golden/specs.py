@@ -57,6 +57,10 @@ CASES = {
                          is_q_zCct=True, n_z=8, loss="sumo"),
     "g10_attnlnp_nll_nz8": dict(kind="AttnLNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=12, T=20, is_q_zCct=True, n_z=8,
                                 loss="nll"),
+    # G13: layers wider than 256 features train too (the reference's MLPs have no width limit, mlp.py:44-93): the
+    # config-5 decoder width as a train step (weight gradients in 256 x 256 blocks, 32-block chain instance)
+    "g13_cnp_r512": dict(kind="CNP", r=512, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=40, T=100),
+    "g13_attncnp_r512": dict(kind="AttnCNP", r=512, L_xy=1, L_dec=2, dx=1, dy=2, B=2, C=40, T=70),
     "g8_attnlnp_transformer": dict(kind="AttnLNP", r=128, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=33, T=40,
                                    attention="transformer", is_q_zCct=True, n_z=2),
 }

@@ -164,18 +164,25 @@ def test_decode_only_r512_matches_reference():
     np.testing.assert_allclose(p.base_dist.scale.cpu().numpy(), g["scale"], rtol=1e-5)
 
 
-def test_training_wider_than_256_is_refused_loudly():
+def test_training_wider_than_256_features():
+    """A 512-wide MLP trains (the reference has no width limit, npf/architectures/mlp.py:44-93): forward on the 32-block
+    chain instance, input gradient by its dgrad, weight gradients as 256 x 256 block jobs of the wgrad kernel."""
     import npf_gwwaveform_amd as A
 
-    m = A.MLP(512, 512, hidden_size=512).to(DEV)
-    x = torch.randn(64, 512, device=DEV, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="backward kernels"):
-        m(x)
-    with torch.no_grad():
-        y = m(x)
-    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, m.to_hidden.weight, m.to_hidden.bias)),
-                                     m.out.weight, m.out.bias)
-    assert_close(y, ref, what="512-wide MLP inference")
+    torch.manual_seed(0)
+    m = A.MLP(512, 512, hidden_size=512, n_hidden_layers=2).to(DEV)
+    x = torch.randn(70, 512, device=DEV, requires_grad=True)
+    w = torch.randn(70, 512, device=DEV)
+    (m(x) * w).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    F = torch.nn.functional
+    h = torch.relu(F.linear(xr, ps["to_hidden.weight"], ps["to_hidden.bias"]))
+    h = torch.relu(F.linear(h, ps["linears.0.weight"], ps["linears.0.bias"]))
+    (F.linear(h, ps["out.weight"], ps["out.bias"]) * w).sum().backward()
+    assert_close(x.grad, xr.grad, tol=1e-4, what="dx of a 512-wide MLP")
+    for k, p in m.named_parameters():
+        assert_close(p.grad, ps[k].grad, tol=1e-4, what=f"grad {k}")
 
 
 def test_training_inputs_outside_unit_range_raise_like_the_reference():

@@ -31,6 +31,11 @@ SWEEP = {
     # g3 / g4 of this size only store norms and 64-entry heads)
     "attncnp_c2_full": dict(kind="AttnCNP", r=256, L_xy=4, L_dec=4, dx=1, dy=2, B=2, C=256, T=1024),
     "attnlnp_c2_full": dict(kind="AttnLNP", r=256, L_xy=4, L_dec=4, dx=1, dy=2, B=2, C=256, T=1024, is_q_zCct=True, n_z=1),
+    # wider than 256 features: 32-block chain instance, weight gradients in 256 x 256 blocks (full gradients vs the oracle)
+    "cnp_r512": dict(kind="CNP", r=512, L_xy=1, L_dec=2, dx=1, dy=2, B=2, C=33, T=70),
+    "cnp_r384_L2": dict(kind="CNP", r=384, L_xy=2, L_dec=2, dx=2, dy=1, B=2, C=20, T=45),
+    "attncnp_r512": dict(kind="AttnCNP", r=512, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=37, T=50),
+    "attnlnp_r320_nz2": dict(kind="AttnLNP", r=320, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=21, T=40, is_q_zCct=True, n_z=2),
     "attncnp_r44": dict(kind="AttnCNP", r=44, L_xy=2, L_dec=2, dx=1, dy=1, B=2, C=3, T=9),
     "attnlnp_nz3_r64": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=40, T=48, is_q_zCct=True, n_z=3),
     # more context points than one fused score row holds: blocked softmax (attention_long.py)

@@ -42,7 +42,7 @@ def test_abi_struct_sizes_match_header():
 
     assert ctypes.sizeof(_lib.NpfOp) == 72
     assert ctypes.sizeof(_lib.NpfProgram) == 32 + 72 * 40
-    assert ctypes.sizeof(_lib.NpfWgradJob) == 56
+    assert ctypes.sizeof(_lib.NpfWgradJob) == 72
     hdr = open(os.path.join(ROOT, "include", "npf_hip.h")).read()
     assert f"#define NPF_MAX_OPS {_lib.NPF_MAX_OPS}" in hdr
     assert f"#define NPF_MAX_FEATURES {_lib.NPF_MAX_FEATURES}" in hdr
