@@ -151,28 +151,83 @@ class Trainer:
             self._sched.step()
         return self.opt.param_groups[0]["lr"]
 
+    # The reference checkpoints through skorch's ``Checkpoint`` callback (utils/train.py:203-221): ``params.pt`` = the
+    # module's state_dict, ``optimizer.pt`` = ``torch.optim.Adam(module.parameters()).state_dict()`` -- one
+    # ``exp_avg`` / ``exp_avg_sq`` / ``step`` entry PER PARAMETER, in ``module.parameters()`` order -- and
+    # ``history.json``.  This Trainer runs Adam on ONE flat buffer; the two functions below translate.
+    def optimizer_state_dict(self) -> dict:
+        """Adam's state in the per-parameter layout of ``torch.optim.Adam(model.parameters())`` (what skorch writes to
+        ``optimizer.pt``): every parameter's moments are the matching slice of the flat moments."""
+        flat_sd = self.opt.state_dict()
+        group = {k: v for k, v in flat_sd["param_groups"][0].items() if k != "params"}
+        group["fused"] = None  # (how THIS process steps is not part of the optimisation state)
+        group["capturable"] = False
+        group["params"] = list(range(len(self.flat.params)))
+        state = {}
+        st = self.opt.state.get(self.flat.flat)
+        if st:
+            step = st["step"].detach().float().cpu().reshape(()) if torch.is_tensor(st["step"]) else torch.tensor(float(st["step"]))
+            for i, (p, o, n) in enumerate(zip(self.flat.params, self.flat.offsets, self.flat.sizes)):
+                state[i] = {"step": step.clone(),
+                            "exp_avg": st["exp_avg"][o:o + n].detach().view_as(p).cpu().clone(),
+                            "exp_avg_sq": st["exp_avg_sq"][o:o + n].detach().view_as(p).cpu().clone()}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Inverse of :meth:`optimizer_state_dict`; also takes an ``optimizer.pt`` written by the reference's skorch
+        harness for the same model (same parameters in the same order), or this Trainer's older flat layout."""
+        groups, state = sd["param_groups"], sd["state"]
+        if len(groups) != 1:
+            raise ValueError("optimizer state with several parameter groups")
+        ids = list(groups[0]["params"])
+        dev = self.flat.flat.device
+        if len(ids) == 1 and len(self.flat.params) != 1:  # the flat layout (one parameter = the whole buffer)
+            self.opt.load_state_dict(sd)
+        else:
+            if len(ids) != len(self.flat.params):
+                raise ValueError(f"optimizer state for {len(ids)} parameters, the model has {len(self.flat.params)}")
+            for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+                if k in groups[0]:
+                    self.opt.param_groups[0][k] = groups[0][k]
+            if state:
+                exp_avg, exp_avg_sq = torch.zeros_like(self.flat.flat.data), torch.zeros_like(self.flat.flat.data)
+                steps = set()
+                for pid, p, o, n in zip(ids, self.flat.params, self.flat.offsets, self.flat.sizes):
+                    e = state[pid]
+                    if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state of parameter {pid} has shape {tuple(e['exp_avg'].shape)}, "
+                                         f"the model's is {tuple(p.shape)}")
+                    exp_avg[o:o + n].copy_(e["exp_avg"].reshape(-1))
+                    exp_avg_sq[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
+                    steps.add(float(e["step"]))
+                if len(steps) != 1:
+                    raise ValueError("per-parameter step counts differ: not one Adam run over all parameters")
+                st = self.opt.state[self.flat.flat]
+                like = st.get("step")
+                step = torch.tensor(steps.pop(), dtype=torch.float32)
+                st["step"] = step.to(like.device) if torch.is_tensor(like) else (step.to(dev) if self.flat.flat.is_cuda else step)
+                st["exp_avg"], st["exp_avg_sq"] = exp_avg, exp_avg_sq
+
     def save_checkpoint(self, dirname: str, history: Optional[list] = None) -> None:
-        """skorch ``Checkpoint`` layout: ``params.pt`` = the module's state_dict (the reference's key
-        names, loadable by the reference and by ``load_state_dict`` here), ``optimizer.pt``,
-        ``history.json``.  The optimizer state is Adam's on the *flat* parameter buffer (one
-        exp_avg / exp_avg_sq vector): it resumes this Trainer, it is not skorch's per-tensor state."""
+        """skorch ``Checkpoint`` layout, interchangeable with the reference's: ``params.pt`` = the module's state_dict
+        (the reference's key names), ``optimizer.pt`` = the per-parameter Adam state, ``history.json``."""
         os.makedirs(dirname, exist_ok=True)
         torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, os.path.join(dirname, "params.pt"))
-        torch.save(self.opt.state_dict(), os.path.join(dirname, "optimizer.pt"))
+        torch.save(self.optimizer_state_dict(), os.path.join(dirname, "optimizer.pt"))
         with open(os.path.join(dirname, "history.json"), "w") as f:
             json.dump(history or [], f)
 
     def load_checkpoint(self, dirname: str, load_optimizer: bool = True) -> list:
-        """Inverse of :meth:`save_checkpoint`; ``params.pt`` may also be one written by the reference
-        (e.g. ``results/pretrained/*/run_0/params.pt``).  Loaded with ``weights_only=True``."""
+        """Inverse of :meth:`save_checkpoint`; ``params.pt`` / ``optimizer.pt`` may also be ones written by the reference
+        (e.g. ``results/pretrained/*/run_0/``).  Loaded with ``weights_only=True``."""
         sd = torch.load(os.path.join(dirname, "params.pt"), map_location="cpu", weights_only=True)
         self.model.load_state_dict(sd, strict=True)  # parameters are views of the flat buffer: copied in place
         opt_path = os.path.join(dirname, "optimizer.pt")
         if load_optimizer and os.path.exists(opt_path):
             try:
-                self.opt.load_state_dict(torch.load(opt_path, map_location=self.flat.flat.device, weights_only=True))
-            except (ValueError, KeyError, RuntimeError) as e:  # e.g. skorch's per-tensor optimizer state
-                raise ValueError(f"{opt_path} does not hold this Trainer's flat Adam state: {e}") from e
+                self.load_optimizer_state_dict(torch.load(opt_path, map_location="cpu", weights_only=True))
+            except (KeyError, RuntimeError) as e:
+                raise ValueError(f"{opt_path} does not hold an Adam state for this model: {e}") from e
         self.sync_replicas()  # (ranks that loaded nothing, or something else, follow rank 0)
         hist = os.path.join(dirname, "history.json")
         return json.load(open(hist)) if os.path.exists(hist) else []

@@ -340,3 +340,73 @@ def test_trainer_checkpoint_and_lr_schedule_glue(tmp_path):
         assert torch.equal(a, b), k
     assert t2.flat.params[0].data_ptr() == t2.flat.flat.data_ptr()  # still views of the flat buffer
     assert abs(t2.opt.param_groups[0]["lr"] - 1e-4) < 1e-12
+
+
+def _cnp_like_the_shipped_checkpoint():
+    import warnings
+    from functools import partial
+
+    import npf_gwwaveform_amd as A
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return A.CNP(1, 1, r_dim=128,
+                     XYEncoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=2, hidden_size=256), is_sum_merge=True))
+
+
+def test_optimizer_state_is_interchangeable_with_per_parameter_adam():
+    """``optimizer.pt`` in skorch's layout (utils/train.py:203-221): the flat Adam state exported per parameter loads
+    into a plain ``torch.optim.Adam(model.parameters())`` and both then take the same step; and back."""
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd.train import Trainer
+
+    torch.manual_seed(1)
+    m1, m2 = _cnp_like_the_shipped_checkpoint(), _cnp_like_the_shipped_checkpoint()
+    m2.load_state_dict(m1.state_dict())
+    t1 = Trainer(m1, A.CNPFLoss(), lr=1e-3, world=1)
+    ref_opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(2)
+    for step in range(3):  # same synthetic gradients on both sides
+        grads = [torch.randn(p.shape, generator=g) for p in m2.parameters()]
+        for p, gr in zip(m2.parameters(), grads):
+            p.grad = gr.clone()
+        ref_opt.step()
+        t1.flat.flat.grad = torch.cat([gr.reshape(-1) for gr in grads])
+        t1.opt.step()
+        if step == 1:  # hand the state over in both directions mid-run
+            exported = t1.optimizer_state_dict()
+            assert sorted(exported["state"]) == list(range(len(t1.flat.params)))
+            fresh = torch.optim.Adam(m2.parameters(), lr=1e-3)
+            fresh.load_state_dict(exported)          # a per-parameter Adam accepts it
+            t1.load_optimizer_state_dict(ref_opt.state_dict())  # and the Trainer accepts the per-parameter one
+            ref_opt = fresh
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7, msg=k)
+
+
+def test_shipped_skorch_optimizer_state_loads(tmp_path):
+    """The ``optimizer.pt`` the reference ships next to its pretrained CNP (written by skorch's Checkpoint) loads into
+    the Trainer: every parameter's moments land in its slice of the flat buffers."""
+    import shutil
+
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd.train import Trainer
+
+    src = "/root/reference/results/pretrained/RBF_Kernel/CNP/run_0"
+    if not os.path.exists(os.path.join(src, "optimizer.pt")):
+        pytest.skip("the reference checkout is not present on this box")
+    for f in ("params.pt", "optimizer.pt"):
+        shutil.copy(os.path.join(src, f), tmp_path / f)
+    t = Trainer(_cnp_like_the_shipped_checkpoint(), A.CNPFLoss(), lr=1e-3, world=1)
+    t.load_checkpoint(str(tmp_path))
+    sd = torch.load(tmp_path / "optimizer.pt", map_location="cpu", weights_only=True)
+    st = t.opt.state[t.flat.flat]
+    for pid, p, o, n in zip(sd["param_groups"][0]["params"], t.flat.params, t.flat.offsets, t.flat.sizes):
+        assert torch.equal(st["exp_avg"][o:o + n].view_as(p), sd["state"][pid]["exp_avg"])
+        assert torch.equal(st["exp_avg_sq"][o:o + n].view_as(p), sd["state"][pid]["exp_avg_sq"])
+    assert float(st["step"]) == float(sd["state"][sd["param_groups"][0]["params"][0]]["step"]) > 0
+    assert abs(t.opt.param_groups[0]["lr"] - sd["param_groups"][0]["lr"]) < 1e-12
+    back = t.optimizer_state_dict()  # (re-keyed 0 .. n-1 as current torch writes it; the shipped file is keyed by id())
+    for i, pid in enumerate(sd["param_groups"][0]["params"]):
+        assert torch.equal(back["state"][i]["exp_avg"], sd["state"][pid]["exp_avg"])
+        assert float(back["state"][i]["step"]) == float(sd["state"][pid]["step"])
