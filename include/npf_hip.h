@@ -89,6 +89,11 @@ enum npf_opcode {
   NPF_OP_STORE_TRB = 19,   /* bf16 mode only: p0 [task][i0 features][i1 = 32*tiles columns] bf16 <- cur, the
                               transposed image W[n = feature][k = point], points k-permuted in groups of 32  */
   NPF_OP_LOAD_RM = 17,     /* cur <- row-major p0 [task][pt][i0], i0 % 32 == 0, i0 <= 512 (i4 = modulus)  */
+  NPF_OP_STORE_MASK = 20,  /* bf16 mode only: PTM tensor p0 <- (cur > 0) as bits (i0 = F <= 256): the ReLU mask of the
+                              backward pass -- one 32-bit word per point, lane group g = (feature / 4) % 4 and 128
+                              features, [task][tile][ceil(F/128) words][4 g][32 points]; within a word the 16-feature
+                              block bb = (feature / 16) % 8, element e = feature % 4 sits at bit 31 - (4 bb + e)        */
+  NPF_OP_MASK_BITS = 21,   /* bf16 mode only: cur <- (bit of PTM tensor p0) ? cur : 0 (i0 = F)   [relu backward]      */
   NPF_OP_LAYERNORM_BWD = 16 /* cur = dy on entry; x = PT32 p0 (the forward input, i0 = F), gamma p1:
                               xhat = (x - mean) rstd;  PT32 p2 <- dy * xhat (for dgamma);
                               cur <- rstd (g - mean(g) - xhat mean(g xhat)),  g = dy * gamma      */
@@ -108,6 +113,7 @@ enum npf_wmode {
 #define NPF_F_P16 16u     /* bf16 mode only: the op's PT tensor (p0 of LOAD_PT / STORE_PT / ADD_PT / MASK_POS /
                             ROWDOT_PT / SOFTMAX_BWD, p2 of a LINEAR's addend or mask) is a PT16 tensor: bf16 tiles
                             [F/8 rows][32 points][8 features], row 4s+g = features {32s+4g+i}, {32s+16+4g+i}     */
+#define NPF_F_MASK_BITS 32u /* bf16 mode only: like MASK_PT with the mask as bits, p2 = PTM tensor (NPF_OP_STORE_MASK)   */
 #define NPF_F_ADD_RM 8u  /* like ADD_PT with a row-major addend p2 [task][pt][i1] (i1 % 32 == 0): module-
                             boundary tensors enter without a layout pass (inference paths)            */
 

@@ -21,10 +21,11 @@ NPF_MAX_FUSED_ROW = 256       # features of one fused attention score row / Laye
 
 # opcodes (enum npf_opcode)
 OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFTMAX, OP_ADD_PT, OP_MASK_POS, \
-    OP_ADD_TASKVEC, OP_ROWDOT_PT, OP_SOFTMAX_BWD, OP_RELU, OP_SCALE, OP_STORE_TR, OP_LAYERNORM, OP_LAYERNORM_BWD, OP_LOAD_RM, OP_STORE_WB, OP_STORE_TRB = range(20)
+    OP_ADD_TASKVEC, OP_ROWDOT_PT, OP_SOFTMAX_BWD, OP_RELU, OP_SCALE, OP_STORE_TR, OP_LAYERNORM, OP_LAYERNORM_BWD, OP_LOAD_RM, OP_STORE_WB, OP_STORE_TRB, \
+    OP_STORE_MASK, OP_MASK_BITS = range(22)
 # weight modes (enum npf_wmode)
 W_ROWMAJOR, W_PT_ROWS, W_PT_COLS = range(3)
-F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16 = 1, 2, 4, 8, 16
+F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16, F_MASK_BITS = 1, 2, 4, 8, 16, 32
 
 
 class NpfOp(C.Structure):

@@ -29,6 +29,7 @@ DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microben
 # tests / tools: 1 = 64-point workgroups, 2 = 128-point (paired) workgroups, 0 = the library's choice
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 PT16_INTERNAL = os.environ.get("NPF_NO_PT16", "0") != "1"  # bf16 mode: backward-only tensors as bf16 tiles (debug switch)
+MASK_BITS = os.environ.get("NPF_NO_MASK_BITS", "0") != "1"  # bf16 mode: ReLU masks of the backward pass as bits (debug switch)
 
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
@@ -88,6 +89,12 @@ def pt16_shape(n_tasks: int, pts: int, F: int):
 
 def pt16_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
     return torch.empty(pt16_shape(n_tasks, pts, F), dtype=torch.bfloat16, device=device)
+
+
+def ptm_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
+    """PTM: a ReLU mask as bits (bf16 compute mode, ``NPF_OP_STORE_MASK``) -- [n_tasks, tiles, ceil(F / 128) words, 4 lane
+    groups, 32 points] int32, 32 bytes per point and 256 features."""
+    return torch.empty((n_tasks, tiles_of(pts), (pad32(F) + 127) // 128, 4, 32), dtype=torch.int32, device=device)
 
 
 def pt_empty(n_tasks: int, pts: int, F: int, device) -> torch.Tensor:
@@ -182,6 +189,25 @@ class Program:
         p, fl = self._pt(t)
         self._op(op=L.OP_MASK_POS, i0=pad32(F), p0=p, flags=fl)
 
+    def store_mask(self, m, F):
+        """PTM tensor ``m`` <- (cur > 0) as bits (bf16 programs)."""
+        self.bf16 = True
+        self.keep.append(m)
+        self._op(op=L.OP_STORE_MASK, i0=pad32(F), p0=m.data_ptr())
+
+    def mask_bits(self, m, F):
+        """cur <- bit ? cur : 0 with the PTM tensor ``m``; fused into the producing layer's epilogue when there is one."""
+        self.bf16 = True
+        self.keep.append(m)
+        last = self.ops[-1] if self.ops else None
+        if (last is not None and last.op == L.OP_LINEAR and pad32(last.i1) == pad32(F)
+                and not (last.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_RELU | L.F_MASK_BITS))):
+            last.flags |= L.F_MASK_BITS
+            last.p2 = m.data_ptr()
+            last.i4 = 0
+            return
+        self._op(op=L.OP_MASK_BITS, i0=pad32(F), p0=m.data_ptr())
+
     def rowdot_pt(self, t, F):
         p, fl = self._pt(t)
         self._op(op=L.OP_ROWDOT_PT, i0=pad32(F), p0=p, flags=fl)
@@ -272,6 +298,8 @@ class Program:
                 per_pt += 4 * o.i0
             elif o.op in (L.OP_STORE_WB, L.OP_STORE_TRB):
                 per_pt += 2 * pad32(o.i0)
+            elif o.op in (L.OP_STORE_MASK, L.OP_MASK_BITS):
+                per_pt += 16 * ((o.i0 + 127) // 128)
             elif o.op == L.OP_SOFTMAX and o.i1:
                 per_pt += 8
             elif o.op == L.OP_LAYERNORM_BWD:
@@ -279,6 +307,8 @@ class Program:
             elif o.op == L.OP_LINEAR:
                 if o.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_ADD_RM):
                     per_pt += (2 if o.flags & L.F_P16 else 4) * pad32(o.i1)
+                if o.flags & L.F_MASK_BITS:
+                    per_pt += 16 * ((pad32(o.i1) + 127) // 128)
                 per_task = o.i2 != L.W_ROWMAJOR or o.s0 != 0
                 fixed += 4 * o.i0 * o.i1 * (self.n_tasks if per_task else 1)
         return per_pt * pts + fixed
@@ -642,6 +672,17 @@ class _ChainFn(torch.autograd.Function):
                 prog.store_pt(backed, F)
             return backed
 
+        def save_relu_mask(i, F):
+            """What the backward pass needs of a ReLU output: where it is positive.  bf16 mode: 32 bytes of bits per point
+            (the activation itself is only stored if a wgrad job reads it -- the next layer asks for that itself);
+            fp32 mode: the activation tensor doubles as the mask."""
+            if bf16 and MASK_BITS:
+                m = ptm_empty(chain.n_tasks, chain.pts, F, dev)
+                prog.store_mask(m, F)
+                saved[(i, "mask")] = m
+            else:
+                saved[(i, "out")] = ensure_saved(F, internal=True)
+
         images = {}  # bf16 mode: the weight images of all LINEAR steps, one launch
         if bf16:
             lin = [st.t["W"] for st in chain.steps if st.kind == "linear"]
@@ -681,19 +722,19 @@ class _ChainFn(torch.autograd.Function):
                 backed = backed16 = None
                 upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if train and a["relu"] and upstream:
-                    saved[(i, "out")] = ensure_saved(a["N"], internal=True)
+                    save_relu_mask(i, a["N"])
             elif k == "add_pt":
                 prog.add_pt(T[st.t["x"]], a["F"], a["relu"], a["mod"])
                 backed = backed16 = None
                 upstream = upstream or needs_grad[st.t["x"]]
                 if train and a["relu"] and upstream:
-                    saved[(i, "out")] = ensure_saved(a["F"], internal=True)
+                    save_relu_mask(i, a["F"])
             elif k == "add_taskvec":
                 prog.add_taskvec(T[st.t["v"]], a["F"], a["relu"], a["mod"])
                 backed = backed16 = None
                 upstream = upstream or needs_grad[st.t["v"]]
                 if train and a["relu"] and upstream:
-                    saved[(i, "out")] = ensure_saved(a["F"], internal=True)
+                    save_relu_mask(i, a["F"])
             elif k == "layernorm":
                 gi, bi = st.t["g"], st.t["b"]
                 upstream = upstream or needs_grad[gi] or needs_grad[bi]
@@ -783,6 +824,12 @@ class _ChainFn(torch.autograd.Function):
                 return pt16_empty(chain.n_tasks, chain.pts, F, dev)
             return pt_empty(chain.n_tasks, chain.pts, F, dev)
 
+        def relu_backward(i, F):
+            if (i, "mask") in saved:
+                prog.mask_bits(saved[(i, "mask")], F)
+            else:
+                prog.mask_pos(saved[(i, "out")], F)
+
         def acc_grad(idx, g):
             grads[idx] = g if grads[idx] is None else grads[idx] + g
 
@@ -821,7 +868,7 @@ class _ChainFn(torch.autograd.Function):
             if k == "linear":
                 W, b, add = st.t["W"], st.t["b"], st.t["add"]
                 if a["relu"]:
-                    prog.mask_pos(saved[(i, "out")], a["N"])
+                    relu_backward(i, a["N"])
                 need_dz = needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if need_dz:
                     dz = new_pt(a["N"], internal=not ((add >= 0 and needs_grad[add]) or (b >= 0 and a["bpt"] and needs_grad[b])))
@@ -847,7 +894,7 @@ class _ChainFn(torch.autograd.Function):
                     break
             elif k in ("add_pt", "add_taskvec"):
                 if a["relu"]:
-                    prog.mask_pos(saved[(i, "out")], a["F"])
+                    relu_backward(i, a["F"])
                 idx = st.t["x"] if k == "add_pt" else st.t["v"]
                 if needs_grad[idx]:
                     buf = new_pt(a["F"])

@@ -50,6 +50,25 @@ constexpr int kWaves = 4;  // waves that issue the slab DMA (the first four of a
 constexpr int kSlabRows = 32;
 constexpr int kBlk = kSlabRows / 16;            // 16-row output blocks (accumulators) per slab
 constexpr int slab_floats(int maxb) { return kSlabRows * 16 * maxb + 64; }  // rows, then the biases
+// The slab ring of an instance: fp32 instances 2 slots (3 in the paired variant) of slab_floats(MAXB) floats.  The bf16
+// instance streams half-size slabs (32 rows x 256 bf16 = 4096 floats + biases): FOUR slots fit the same LDS, and its
+// 256 -> 256 layers keep two slabs in flight behind a counted s_waitcnt (fast_layer, RING) -- with one slab in flight
+// and a vmcnt(0) per slab every stage lasts as long as one DMA round trip (~1800 cycles against 256 cycles of MFMA).
+constexpr int kRingFloats = kSlabRows * 128 + 64;
+constexpr bool ring_instance(bool bf16, bool paired) { return bf16 && !paired; }
+constexpr int slot_stride(int maxb, bool bf16, bool paired) { return ring_instance(bf16, paired) ? kRingFloats : slab_floats(maxb); }
+template <bool BF16, bool PAIRED>
+__device__ __forceinline__ int next_slot(int slot) {
+  if constexpr (ring_instance(BF16, PAIRED)) return (slot + 1) & 3;
+  else if constexpr (PAIRED) return slot == 2 ? 0 : slot + 1;
+  else return slot ^ 1;
+}
+
+// ReLU masks as bits ("PTM" tensors, NPF_OP_STORE_MASK / NPF_OP_MASK_BITS / NPF_F_MASK_BITS; bf16 instance): one 32-bit
+// word per point, lane group g and group of 128 features -- [tile][word][g][32 points] -- holding the lane's own 32 values
+// of blocks 8 w .. 8 w + 7: element e of block b = 8 w + bb at bit 31 - (4 bb + e) (the order an add-with-carry chain
+// shifts them in).  32 bytes per point and 256 features instead of the 512 B of the PT16 activation.
+__device__ __forceinline__ bool mask_bit(unsigned word, int bb, int e) { return (word & (0x80000000u >> (4 * bb + e))) != 0u; }
 
 struct Wave {
   int tid, lane, wave;     // wave is wave-uniform (readfirstlane)
@@ -552,11 +571,101 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 #ifndef NPF_DMA_KB0
 #define NPF_DMA_KB0 0  // k-block of the stage's first DMA piece
 #endif
+// RING (bf16 instance, layers without a per-point PT addend: EPI 1 / 0 on the bias alone, or EPI 3 = mask bits): the
+// four-slot ring two slabs deep.  Stage I multiplies slab I (ring slot s0 + I), and inside its MFMA loop issues the DMA of
+// slab I + 2 (stage 0: slabs 1 and 2); it ends with s_waitcnt vmcnt(5) -- slab I + 1 has landed, the five DMA instructions
+// of slab I + 2 may stay in flight -- and a raw s_barrier.  No register-destination load is issued inside the stages (a
+// wait on one would drag every older DMA with it: vmcnt retires in order), the slab's biases are read by inline-asm
+// ds_read (a C++ LDS load behind an LDS-DMA in flight makes hipcc insert vmcnt(0)).  The last stage hands over exactly
+// like the two-slot form: next layer's slab 0 by the generic DMA code, then a full barrier.
+template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class NextLayer>
+__device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB], f32x4 (&out)[MAXB],
+                                                const SlabOp& op, const unsigned* mbits, NextLayer next_layer) {
+  static_assert(BF16 && !PAIRED && NB >= 3 && (EPI == 0 || EPI == 1 || EPI == 3), "ring variant");
+  constexpr int Kp = 16 * KB16S;
+  constexpr int NPW = Kp / 32;
+  constexpr int E = KB16S >= 8 ? 4 : (KB16S >= 4 ? 2 : 1);
+  constexpr int PPB = 4 / E;
+  unsigned mw[2] = {0u, 0u};
+  if constexpr (EPI == 3) {  // the whole layer's mask: two words per lane, first used in stage 1
+    mw[0] = mbits[0];
+    if constexpr (NB > 4) mw[1] = mbits[128];
+  }
+  bf16x8 curb[MAXB / 2] = {};
+#pragma unroll
+  for (int st = 0; st < KB16S; ++st) curb[st] = pack_bf16(cur[2 * st], cur[2 * st + 1]);
+  auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
+    const int j = part >> 1, e0 = (part & 1) * 2;
+    f32x4 o = out[2 * I + j];
+#pragma unroll
+    for (int e = e0; e < e0 + 2; ++e) {
+      if constexpr (EPI == 3) o[e] = mask_bit(mw[(2 * I + j) >> 3], (2 * I + j) & 7, e) ? o[e] : 0.f;
+      else if constexpr (EPI == 1) o[e] = fmaxf(o[e], 0.f);
+    }
+    out[2 * I + j] = o;
+  };
+  const char* wbase = (const char*)op.W;
+  const float* bias_src = op.bias;
+  const int slab_stride = op.slab_stride, step = op.step;
+  unsigned lo[2] = {op.lo[0], op.lo[1]};  // (bf16 256-wide rows: 2 rows per piece, the swizzle repeats every 2 pieces)
+  const int s0 = slot;
+  // DMA piece i (i < NPW: weights, i == NPW: the biases) of slab `sb` into ring slot (s0 + sb) & 3
+  auto issue = [&](int sb, int i) __attribute__((always_inline)) {
+    float* dst = smem + ((s0 + sb) & 3) * kRingFloats;
+    if (i < NPW) {
+      dma16_so(wbase + (size_t)sb * slab_stride * 4 + (size_t)(i * step) * 4, lo[i & 1], dst + w.wave * 256 + i * (kWaves * 256));
+    } else {
+      const char* bsrc = bias_src != nullptr ? (const char*)(bias_src + sb * kSlabRows) : (const char*)g_zero128;
+      dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, dst + kSlabRows * Kp);
+    }
+  };
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const float* sl = smem + ((s0 + I) & 3) * kRingFloats;
+    if (I == NB - 1) next_layer(smem + ((s0 + NB) & 3) * kRingFloats);  // slab 0 of the next LINEAR: `op` changes here
+    {  // the slab's biases initialise its two accumulators
+      const unsigned ba = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(sl + kSlabRows * Kp + 4 * w.g);
+      asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(out[2 * I]), "=&v"(out[2 * I + 1])
+                   : "v"(ba));
+    }
+    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+      if (I > 0 && kb < E) {
+#pragma unroll
+        for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
+      }
+      if (I == 0) {  // slabs 1 and 2: 2 (NPW + 1) instructions over the KB16S k-steps
+        constexpr int per = (2 * (NPW + 1) + KB16S - 1) / KB16S;
+#pragma unroll
+        for (int u = 0; u < per; ++u) {
+          const int n = kb * per + u;
+          if (n < NPW + 1) issue(1, n);
+          else if (n < 2 * (NPW + 1)) issue(2, n - (NPW + 1));
+        }
+      } else if (I + 2 < NB) {
+        if (kb <= NPW) issue(I + 2, kb);
+      }
+    });
+    if (I == NB - 1) {
+      __syncthreads();  // (vmcnt(0): the next layer's slab 0 has landed)
+    } else {
+      if (I + 2 < NB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  slot = (s0 + NB) & 3;
+#pragma unroll
+  for (int part = 0; part < 4; ++part) epi_part(NB - 1, part);
+#pragma unroll
+  for (int b = 0; b < 2 * NB; ++b) cur[b] = out[b];
+}
+
 template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class NextLayer>
 __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB],
                                            f32x4 (&out)[MAXB], const SlabOp& op, bool issuer, bool grp_b,
                                            const float* addt, int astep, NextLayer next_layer) {
-  constexpr int kSlabFloats = slab_floats(MAXB);
+  constexpr int kSlabFloats = slot_stride(MAXB, BF16, PAIRED);
   constexpr int Kp = 16 * KB16S;
   constexpr int NPW = Kp / 32;                                  // DMA pieces per wave per slab
   constexpr int E = KB16S >= 8 ? 4 : (KB16S >= 4 ? 2 : 1);      // blocks that carry the previous epilogue
@@ -589,7 +698,7 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
   const char* wbase = (const char*)op.W;
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
-    const int nxt = PAIRED ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+    const int nxt = next_slot<BF16, PAIRED>(slot);
     float* nslot = smem + nxt * kSlabFloats;
     const float* sl = smem + slot * kSlabFloats;
     if (I == NB - 1 && issuer) next_layer(nslot);  // slab 0 of the next LINEAR (generic DMA): `op` changes here
@@ -669,10 +778,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int MAXB, int WAVES, bool EXTRA, int FKB, int FNB, bool BF16>
 __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) void chain_kernel(const npf_program_t g) {
   constexpr int kMaxB16 = MAXB;
-  constexpr int kSlabFloats = slab_floats(MAXB);
   constexpr int kTilesPerWG = WAVES / 2;
   constexpr bool kPaired = WAVES == 8;
-  constexpr int kSlots = kPaired ? 3 : 2;
+  constexpr int kSlabFloats = slot_stride(MAXB, BF16, kPaired);  // floats between ring slots
+  constexpr int kSlots = ring_instance(BF16, kPaired) ? 4 : (kPaired ? 3 : 2);
   __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats];
 
   Wave w;
@@ -771,6 +880,15 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       const int NB = (N + kSlabRows - 1) / kSlabRows;
       const bool relu = (o.flags & NPF_F_RELU) != 0;
       const bool mask = (o.flags & NPF_F_MASK_PT) != 0;  // out = (tile > 0) ? acc : 0  (relu backward)
+      // bf16 instance: the same with the mask as bits (PTM tensor p2, two words per lane and 256 features)
+      [[maybe_unused]] const bool maskb = BF16 && (o.flags & NPF_F_MASK_BITS) != 0;
+      [[maybe_unused]] const unsigned* mbits = (const unsigned*)Z;
+      if constexpr (BF16) {
+        if (maskb) {
+          const size_t tile = (size_t)eff_task(w, o.i4) * g.tiles_per_task + w.tile_in_task;
+          mbits = (const unsigned*)o.p2 + (tile * ((N + 127) >> 7) * 4 + w.g) * 32 + 16 * w.half + w.p;  // word q at + 128 q
+        }
+      }
       const bool add = ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid & !(BF16 && (o.flags & NPF_F_P16));
       [[maybe_unused]] const bool add16 = BF16 && ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) != 0) & w.valid & ((o.flags & NPF_F_P16) != 0);
       const bool add_rm = ((o.flags & NPF_F_ADD_RM) != 0) & w.valid;  // row-major addend: feature quad stride 4 floats
@@ -805,7 +923,23 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
               advance();
             }
           };
-          if (mask && p16) {
+          bool done = false;
+          if constexpr (ring_instance(BF16, kPaired)) {
+            // two slabs in flight: every layer that needs no per-point tensor inside its stages
+            const bool plain = (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) == 0;
+            if (maskb) {
+              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, next_layer);
+              done = true;
+            } else if (plain && relu) {
+              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, next_layer);
+              done = true;
+            } else if (plain) {
+              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, next_layer);
+              done = true;
+            }
+          }
+          if (done) {
+          } else if (mask && p16) {
             if constexpr (BF16)
               fast_layer<2, FKB, FNB, MAXB, kPaired, BF16, true>(w, smem, slot, cur, out, pfs, issuer, grp_b, (const float*)addt16, 0, next_layer);
           } else if (mask) fast_layer<2, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, issuer, grp_b, addt, astep, next_layer);
@@ -817,6 +951,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       // queue (out[] shifts down by one slab per iteration), so the loop body exists once
       // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
       // cache) and no dynamically indexed register array is needed.
+      [[maybe_unused]] unsigned gmw[2] = {0u, 0u};
+      if constexpr (BF16) {
+        if (maskb && w.valid) {
+          gmw[0] = mbits[0];
+          if (N > 128) gmw[1] = mbits[128];
+        }
+      }
       for (int nb = 0; nb < NB; ++nb) {
         // 1. addend tiles (consumed after the barrier).  Before the slab DMA: hipcc guards the reuse of the
         // addend registers with a full vmcnt drain, which must not include the DMA issued for the next slab
@@ -833,7 +974,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         // 2. start filling the other slot with the next slab (possibly the next layer's)
         if (!grp_b) NPF_STAMP(4)  // (group A) loop back-edge; (without stamps: the statement below is its body)
         if (pf.op < g.n_ops) {
-          const int nslot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+          const int nslot = next_slot<BF16, kPaired>(slot);
           SlabDma d = dma_begin(pfs, pf.nb, w, smem + nslot * kSlabFloats, !(g.reserved[0] & 1));
           NPF_STAMP(6)  // loop top
           dma_finish(pfs, d, w);
@@ -863,13 +1004,20 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         NPF_STAMP(1)  // addend loads + MFMA loop
         if (!grp_b && !(g.reserved[0] & 4)) __syncthreads();  // slab consumed; vmcnt(0) lands the next one
         NPF_STAMP(2)  // barrier (+ wait for the DMA)
-        slot = kPaired ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+        slot = next_slot<BF16, kPaired>(slot);
 #pragma unroll
         for (int b = 0; b < kMaxB16 - kBlk; ++b) out[b] = out[b + kBlk];
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) {
           f32x4 v;
-          if (mask) {
+          if (maskb) {
+            if constexpr (BF16) {
+              const int blk = kBlk * nb + j;  // (uniform) the block: word blk >> 3, bits 31 - 4 (blk & 7) - e
+              const unsigned word = (blk >= 8 ? gmw[1] : gmw[0]) << (4 * (blk & 7));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (word & (0x80000000u >> e)) ? acc[j][e] : 0.f;
+            }
+          } else if (mask) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ad[j][e] > 0.f ? acc[j][e] : 0.f;
           } else {
@@ -927,6 +1075,38 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         }
       }
       if (opc == NPF_OP_ROWDOT_PT) acc_dot = xg_sum(dot);
+    } else if (BF16 && (opc == NPF_OP_STORE_MASK || opc == NPF_OP_MASK_BITS)) {
+      if constexpr (BF16) {
+        // STORE_MASK: PTM tensor p0 <- (cur > 0), i0 = F;  MASK_BITS: cur <- bit ? cur : 0
+        const int FB = o.i0 >> 4;
+        const size_t tile = (size_t)eff_task(w, o.i4) * g.tiles_per_task + w.tile_in_task;
+        unsigned* t = (unsigned*)o.p0 + (tile * ((o.i0 + 127) >> 7) * 4 + w.g) * 32 + 16 * w.half + w.p;
+#pragma unroll
+        for (int q = 0; q < kMaxB16 / 8; ++q) {
+          if (8 * q < FB) {
+            if (opc == NPF_OP_STORE_MASK) {
+              unsigned word = 0u;
+#pragma unroll
+              for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float x = (8 * q + bb < FB) ? cur[8 * q + bb][e] : 0.f;
+                  // word = 2 word + (x > 0): one compare and one add-with-carry per value
+                  asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(x) : "vcc");
+                }
+              if (w.valid) t[128 * q] = word;
+            } else {
+              const unsigned word = w.valid ? t[128 * q] : 0u;
+#pragma unroll
+              for (int bb = 0; bb < 8; ++bb)
+                if (8 * q + bb < FB) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) cur[8 * q + bb][e] = mask_bit(word, bb, e) ? cur[8 * q + bb][e] : 0.f;
+                }
+            }
+          }
+        }
+      }
     } else if (opc == NPF_OP_LOAD_RM) {
       const int FB = o.i0 >> 4;
       const float* t = rm_lane(o.p0, g, w, pt, o.i0, o.i4) + 4 * w.g;
@@ -1183,6 +1363,10 @@ static int validate(const npf_program_t* g) {
         if (o.i2 != NPF_W_ROWMAJOR && (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
         if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) && (!o.p2 || (((uintptr_t)o.p2) & 15))) return NPF_EINVAL;
         if ((o.flags & NPF_F_ADD_PT) && (o.flags & NPF_F_MASK_PT)) return NPF_EINVAL;
+        if (o.flags & NPF_F_MASK_BITS) {  // (bf16 programs only)
+          if (g->reserved[2] != 1 || (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) || !o.p2 || (((uintptr_t)o.p2) & 3))
+            return NPF_EINVAL;
+        }
         if (o.flags & NPF_F_ADD_RM) {
           if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) || !o.p2 || (((uintptr_t)o.p2) & 15) || (o.i1 & 31)) return NPF_EINVAL;
         }
@@ -1195,6 +1379,10 @@ static int validate(const npf_program_t* g) {
       case NPF_OP_ROWDOT_PT:
       case NPF_OP_SOFTMAX_BWD:
         if (o.i0 <= 0 || o.i0 > NPF_MAX_FEATURES || (o.i0 & 31) || !o.p0 || (((uintptr_t)o.p0) & 15)) return NPF_EINVAL;
+        break;
+      case NPF_OP_STORE_MASK:
+      case NPF_OP_MASK_BITS:
+        if (g->reserved[2] != 1 || o.i0 <= 0 || o.i0 > 256 || (o.i0 & 31) || !o.p0 || (((uintptr_t)o.p0) & 3)) return NPF_EINVAL;
         break;
       case NPF_OP_ADD_TASKVEC:
       case NPF_OP_LOAD_RM:
