@@ -160,10 +160,28 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
             m = X_trgt.abs().amax() if X_trgt.numel() else X_trgt.new_zeros(())
             if X_cntxt.numel():
                 m = torch.maximum(m, X_cntxt.abs().amax())
+            if self.validate_inputs == "deferred":
+                # (a step replayed from a HIP graph cannot stop for the host: the reduction stays in the step, the
+                # running maximum -- NaN-propagating -- is read by ``check_deferred_inputs`` at the next sync point)
+                if getattr(self, "_range_seen", None) is None or self._range_seen.device != m.device:
+                    self._range_seen = torch.zeros((), device=m.device)
+                self._range_seen.copy_(torch.maximum(self._range_seen, m))
+                return
             if not (m.item() <= 1.0):
                 lo = min(X_cntxt.min().item() if X_cntxt.numel() else 0.0, X_trgt.min().item())
                 hi = max(X_cntxt.max().item() if X_cntxt.numel() else 0.0, X_trgt.max().item())
                 raise ValueError(f"Features during training should be in [-1,1]. Got [{lo}, {hi}].")
+
+    def check_deferred_inputs(self):
+        """``validate_inputs == "deferred"``: raise the reference's ValueError (base.py:244-247) if any training batch
+        since the last call had features outside [-1, 1] (one host sync, resets the record)."""
+        seen = getattr(self, "_range_seen", None)
+        if seen is None:
+            return
+        worst = seen.item()
+        seen.zero_()
+        if not (worst <= 1.0):
+            raise ValueError(f"Features during training should be in [-1,1]. Got max |x| = {worst}.")
 
     # ------------------------------------------------------------------ PT-level stages
     _attentive = False  # attentive subclasses also keep feature-major copies of keys / values

@@ -56,8 +56,9 @@ class Trainer:
                  bucket_bytes: int = 2 << 20, use_graph: bool = False):
         """``use_graph``: capture the whole step (forward, loss, backward, Adam) in a HIP graph after a few
         eager steps and replay it -- for small models whose step is a string of launch latencies.  Needs
-        fixed batch shapes (a new shape or learning rate re-captures), a single rank, and skips the
-        per-step host-side range check of the inputs (``model.validate_inputs``)."""
+        fixed batch shapes (a new shape or learning rate re-captures) and a single rank.  The range check of
+        the inputs (base.py:241-247) stays in the step as a device reduction; its verdict is read at the next
+        sync point: call :meth:`check_inputs` (e.g. once per epoch) to get the reference's ValueError."""
         self.model, self.criterion = model, criterion
         self.flat = FlatParameters(model.parameters())
         self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
@@ -101,10 +102,16 @@ class Trainer:
             else:
                 st["step"] = float(step_dev.item())
 
-    def step(self, batch: dict) -> torch.Tensor:
-        if self.use_graph:
+    def step(self, batch: dict, eager: bool = False) -> torch.Tensor:
+        """One optimisation step; ``eager``: bypass the captured graph for this step (instrumented runs)."""
+        if self.use_graph and not eager:
             return self._graph_step(batch)
         return self._eager_step(batch)
+
+    def check_inputs(self) -> None:
+        """Graph mode: raise if a batch since the last call had features outside [-1, 1] (one host sync)."""
+        if hasattr(self.model, "check_deferred_inputs"):
+            self.model.check_deferred_inputs()
 
     def _graph_step(self, batch: dict) -> torch.Tensor:
         sig = (tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())), float(self.opt.param_groups[0]["lr"]))
@@ -114,7 +121,11 @@ class Trainer:
             if self._eager_steps < 3:  # allocator warm-up and lazy initialisations happen eagerly
                 self._eager_steps += 1
                 return self._eager_step(batch)
-            was, self.model.validate_inputs = self.model.validate_inputs, False
+            was = self.model.validate_inputs
+            self.model.validate_inputs = "deferred" if was else False
+            # (the running maximum lives outside the graph's memory pool: a tensor created during capture would be
+            # re-initialised by every replay)
+            self.model._range_seen = torch.zeros((), device=self.flat.flat.device)
             try:
                 self._static = {k: v.clone() for k, v in batch.items()}
                 torch.cuda.synchronize()

@@ -540,6 +540,33 @@ def test_graph_captured_step_equals_eager_step_latent_model():
         assert torch.allclose(p_g[k], p_e[k], rtol=1e-6, atol=1e-8), k
 
 
+def test_graph_step_keeps_the_input_range_check_on_the_device():
+    """Trainer(use_graph=True): a replayed step cannot stop for the host, so the range check of base.py:241-247 stays in
+    the step as a device reduction and ``check_inputs()`` raises the reference's ValueError at the next sync point."""
+    import warnings
+
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd.train import Trainer, synthetic_waveform_batch
+
+    torch.manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = A.AttnCNP(1, 2, r_dim=32).to(DEV)
+    tr = Trainer(model, A.CNPFLoss(), lr=1e-3, world=1, use_graph=True)
+    for i in range(6):
+        tr.step(synthetic_waveform_batch(4, 10, 20, 700 + i, DEV))
+    assert tr._graph is not None
+    tr.check_inputs()  # all batches were in range
+    bad = synthetic_waveform_batch(4, 10, 20, 800, DEV)
+    bad["X_trgt"][1, 3, 0] = 1.7
+    tr.step(bad)
+    tr.step(synthetic_waveform_batch(4, 10, 20, 801, DEV))  # (a good batch afterwards does not hide it)
+    with pytest.raises(ValueError, match=r"\[-1,1\]"):
+        tr.check_inputs()
+    tr.step(synthetic_waveform_batch(4, 10, 20, 802, DEV))
+    tr.check_inputs()  # the record was reset
+
+
 def test_graph_step_refuses_a_random_number_of_latent_samples():
     """A scipy random variable as n_z_samples_train is drawn on the host every forward (base.py:478-486): a
     captured graph would freeze one draw, so Trainer(use_graph=True) refuses such a model."""
