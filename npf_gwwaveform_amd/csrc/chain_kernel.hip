@@ -499,10 +499,14 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
     constexpr int kPf = NPF_BF16_PREFETCH;
     static_assert(kPf >= 1 && kPf <= 3 && KB16S > kPf, "prefetch depth");
     f32x4 fq[kPf + 1][2];
+#ifdef NPF_ABL_NO_LDS  // (tools/ring_ablate.py: timing-only builds, results are garbage)
+#define NPF_RD(set, kbn) asm volatile("" : "=v"(fq[set][0]), "=v"(fq[set][1]) : "v"(addr[(kbn)&3]));
+#else
 #define NPF_RD(set, kbn)                                                                \
   asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"         \
                : "=&v"(fq[set][0]), "=&v"(fq[set][1])                                   \
                : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256), "n"(((kbn) >> 2) * 256 + kRowBlk));
+#endif
 #pragma unroll
     for (int i = 0; i < kPf; ++i) { NPF_RD(i, i) }
 #pragma unroll
@@ -519,8 +523,12 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
         else if (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
       }
+#ifdef NPF_ABL_NO_MFMA
+      asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(fq[c][0]), "v"(fq[c][1]), "v"(curb[kb]));
+#else
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][0]), curb[kb], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][1]), curb[kb], acc1, 0, 0, 0);
+#endif
       side(kb);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -571,16 +579,66 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
 #ifndef NPF_DMA_KB0
 #define NPF_DMA_KB0 0  // k-block of the stage's first DMA piece
 #endif
+#ifdef NPF_STAMPS
+// Diagnostic build only (tools/stamp_probe.py): per-phase cycle sums of the slab loop of wave 0
+// of workgroup 0, written to a buffer nothing else reads.
+__device__ unsigned long long g_stamps[16];  // wave 0 (group A), wave 4 (group B, paired variant)
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define NPF_STAMP(i) { const unsigned long long t__ = stamp(); st_sum[i] += t__ - st_last; st_last = t__; }
+#define NPF_STAMP_ARGS , unsigned long long (&st_sum)[8], unsigned long long& st_last
+#define NPF_STAMP_PASS , st_sum, st_last
+#else
+#define NPF_STAMP(i)
+#define NPF_STAMP_ARGS
+#define NPF_STAMP_PASS
+#endif
+
+// The program's op table in LDS (bf16 instance).  The descriptors are kernel arguments: every `g.ops[i].field` is a scalar
+// load whose first touch of a descriptor misses the scalar cache and costs a memory round trip (measured with
+// tools/stamp_probe_bf16.py: ~4800 cycles at the top of EVERY layer, a quarter of the bare bf16 chain) -- and a scalar
+// load cannot be issued ahead, it shares lgkmcnt with the stream of LDS fragment waits.  So the workgroup copies the table
+// to LDS once (vector loads, one round trip), and an op is fetched by nine broadcast ds_read_b64 + readfirstlane.
+constexpr int kOpDwords = sizeof(npf_op_t) / 4;
+static_assert(sizeof(npf_op_t) == 72, "npf_op_t layout");
+__device__ __forceinline__ npf_op_t lds_op(const float* ops_lds, int i) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(ops_lds + i * kOpDwords);
+  u32x2_t r[9];
+  asm volatile(
+      "ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\t"
+      "ds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\tds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56\n\t"
+      "ds_read_b64 %8, %9 offset:64\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8])
+      : "v"(a));
+  unsigned d[kOpDwords];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    d[2 * k] = (unsigned)__builtin_amdgcn_readfirstlane((int)r[k][0]);
+    d[2 * k + 1] = (unsigned)__builtin_amdgcn_readfirstlane((int)r[k][1]);
+  }
+  npf_op_t o;
+  __builtin_memcpy(&o, d, sizeof(o));
+  return o;
+}
+
 // RING (bf16 instance, layers without a per-point PT addend: EPI 1 / 0 on the bias alone, or EPI 3 = mask bits): the
 // four-slot ring two slabs deep.  Stage I multiplies slab I (ring slot s0 + I), and inside its MFMA loop issues the DMA of
 // slab I + 2 (stage 0: slabs 1 and 2); it ends with s_waitcnt vmcnt(5) -- slab I + 1 has landed, the five DMA instructions
 // of slab I + 2 may stay in flight -- and a raw s_barrier.  No register-destination load is issued inside the stages (a
 // wait on one would drag every older DMA with it: vmcnt retires in order), the slab's biases are read by inline-asm
 // ds_read (a C++ LDS load behind an LDS-DMA in flight makes hipcc insert vmcnt(0)).  The last stage hands over exactly
-// like the two-slot form: next layer's slab 0 by the generic DMA code, then a full barrier.
-template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class NextLayer>
-__device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB], f32x4 (&out)[MAXB],
-                                                const SlabOp& op, const unsigned* mbits, NextLayer next_layer) {
+// like the two-slot form: next layer's slab 0 by the generic DMA code, then a full barrier.  The accumulators are `cur`
+// itself (the input lives on as the packed `curb`): no copy back at the end of the layer.
+template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class Peek, class NextLayer>
+__device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB], f32x4 (&)[MAXB],
+                                                const SlabOp& op, const unsigned* mbits, bool pre2, Peek peek,
+                                                NextLayer next_layer NPF_STAMP_ARGS) {
   static_assert(BF16 && !PAIRED && NB >= 3 && (EPI == 0 || EPI == 1 || EPI == 3), "ring variant");
   constexpr int Kp = 16 * KB16S;
   constexpr int NPW = Kp / 32;
@@ -596,69 +654,110 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
   for (int st = 0; st < KB16S; ++st) curb[st] = pack_bf16(cur[2 * st], cur[2 * st + 1]);
   auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
     const int j = part >> 1, e0 = (part & 1) * 2;
-    f32x4 o = out[2 * I + j];
+    f32x4 o = cur[2 * I + j];
 #pragma unroll
     for (int e = e0; e < e0 + 2; ++e) {
       if constexpr (EPI == 3) o[e] = mask_bit(mw[(2 * I + j) >> 3], (2 * I + j) & 7, e) ? o[e] : 0.f;
       else if constexpr (EPI == 1) o[e] = fmaxf(o[e], 0.f);
     }
-    out[2 * I + j] = o;
+    cur[2 * I + j] = o;
   };
   const char* wbase = (const char*)op.W;
   const float* bias_src = op.bias;
   const int slab_stride = op.slab_stride, step = op.step;
   unsigned lo[2] = {op.lo[0], op.lo[1]};  // (bf16 256-wide rows: 2 rows per piece, the swizzle repeats every 2 pieces)
   const int s0 = slot;
-  // DMA piece i (i < NPW: weights, i == NPW: the biases) of slab `sb` into ring slot (s0 + sb) & 3
-  auto issue = [&](int sb, int i) __attribute__((always_inline)) {
+  NPF_STAMP(5)  // layer setup (pack, mask words)
+  // DMA piece i (i < NPW: weights, i == NPW: the biases) of slab `sb` of the layer (wb, bs) into ring slot (s0 + sb) & 3
+  auto issue_of = [&](const char* wb, const float* bs, int sb_src, int sb, int i) __attribute__((always_inline)) {
     float* dst = smem + ((s0 + sb) & 3) * kRingFloats;
+#ifdef NPF_ABL_NO_DMA
+    return;
+#endif
     if (i < NPW) {
-      dma16_so(wbase + (size_t)sb * slab_stride * 4 + (size_t)(i * step) * 4, lo[i & 1], dst + w.wave * 256 + i * (kWaves * 256));
+      dma16_so(wb + (size_t)sb_src * slab_stride * 4 + (size_t)(i * step) * 4, lo[i & 1], dst + w.wave * 256 + i * (kWaves * 256));
     } else {
-      const char* bsrc = bias_src != nullptr ? (const char*)(bias_src + sb * kSlabRows) : (const char*)g_zero128;
+      const char* bsrc = bs != nullptr ? (const char*)(bs + sb_src * kSlabRows) : (const char*)g_zero128;
       dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, dst + kSlabRows * Kp);
     }
   };
+  auto issue = [&](int sb, int i) __attribute__((always_inline)) { issue_of(wbase, bias_src, sb, sb, i); };
+  // CHAINED hand-over: when the next LINEAR is a ring layer of the same shape (`peek`, at the top of stage NB - 2), its
+  // slabs 0 and 1 are simply slabs NB and NB + 1 of this stream -- issued inside stages NB - 2 and NB - 1 like any other,
+  // waited for with the same counted vmcnt -- and that layer starts with `pre2`: only slab 2 left to issue in its stage 0.
+  // Otherwise the last stage hands over through the generic DMA code (slab 0 of whatever comes next, full drain).
+  bool chain = false;
+  const char* nwbase = wbase;
+  const float* nbias = bias_src;
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
     const float* sl = smem + ((s0 + I) & 3) * kRingFloats;
-    if (I == NB - 1) next_layer(smem + ((s0 + NB) & 3) * kRingFloats);  // slab 0 of the next LINEAR: `op` changes here
+    if (I == NB - 2) {  // `op` changes here
+      chain = peek();
+      nwbase = (const char*)op.W;
+      nbias = op.bias;
+      NPF_STAMP(7)  // peek
+    }
+    if (I == NB - 1 && !chain) next_layer(smem + ((s0 + NB) & 3) * kRingFloats);  // slab 0 of the next LINEAR
+#ifdef NPF_ABL_BOUNDARY_ONLY  // nothing of the stage but the hand-over to the next layer
+    if (I == NB - 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    continue;
+#endif
     {  // the slab's biases initialise its two accumulators
       const unsigned ba = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(sl + kSlabRows * Kp + 4 * w.g);
       asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(out[2 * I]), "=&v"(out[2 * I + 1])
+                   : "=&v"(cur[2 * I]), "=&v"(cur[2 * I + 1])
                    : "v"(ba));
     }
-    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, cur[2 * I], cur[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+#ifndef NPF_ABL_NO_EPI
       if (I > 0 && kb < E) {
 #pragma unroll
         for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
       }
+#endif
       if (I == 0) {  // slabs 1 and 2: 2 (NPW + 1) instructions over the KB16S k-steps
         constexpr int per = (2 * (NPW + 1) + KB16S - 1) / KB16S;
 #pragma unroll
         for (int u = 0; u < per; ++u) {
           const int n = kb * per + u;
-          if (n < NPW + 1) issue(1, n);
-          else if (n < 2 * (NPW + 1)) issue(2, n - (NPW + 1));
+          if (n < NPW + 1) {
+            if (!pre2) issue(1, n);
+          } else if (n < 2 * (NPW + 1)) issue(2, n - (NPW + 1));
         }
       } else if (I + 2 < NB) {
         if (kb <= NPW) issue(I + 2, kb);
+      } else {
+        if (chain && kb <= NPW) issue_of(nwbase, nbias, I + 2 - NB, I + 2, kb);
       }
     });
-    if (I == NB - 1) {
+    NPF_STAMP(1)  // bias read + MFMA loop with the DMA issue and the previous slab's epilogue inside
+    if (I + 2 < NB || chain) {  // the slab issued in this stage may stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
+      NPF_STAMP(0)  // counted DMA wait
+#ifndef NPF_ABL_NO_BAR
+      __builtin_amdgcn_s_barrier();
+#endif
+    } else if (I == NB - 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      NPF_STAMP(0)
       __syncthreads();  // (vmcnt(0): the next layer's slab 0 has landed)
     } else {
-      if (I + 2 < NB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      NPF_STAMP(0)
+#ifndef NPF_ABL_NO_BAR
       __builtin_amdgcn_s_barrier();
+#endif
     }
+    NPF_STAMP(2)  // barrier
   }
   slot = (s0 + NB) & 3;
 #pragma unroll
   for (int part = 0; part < 4; ++part) epi_part(NB - 1, part);
-#pragma unroll
-  for (int b = 0; b < 2 * NB; ++b) cur[b] = out[b];
+  NPF_STAMP(6)  // last epilogue
 }
 
 template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class NextLayer>
@@ -672,6 +771,9 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
   constexpr int PPB = 4 / E;                                    // epilogue parts per block
   static_assert(2 * NB <= MAXB && KB16S <= MAXB, "layer does not fit the register file");
   f32x4 ad[2] = {};
+  // bf16: the layer's input lives on as the packed `curb`, so the accumulators ARE `cur` (no copy back: at the interpreter's
+  // back edge that copy is 32 VALU moves issued against the sibling wave's MFMA stream, ~4000 cycles per layer)
+  f32x4 (&acc)[MAXB] = BF16 ? cur : out;
   bf16x8 curb[MAXB / 2] = {};
   if constexpr (BF16) {
 #pragma unroll
@@ -679,7 +781,7 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
   }
   auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
     const int j = part >> 1, e0 = (part & 1) * 2;
-    f32x4 o = out[2 * I + j];
+    f32x4 o = acc[2 * I + j];
 #pragma unroll
     for (int e = e0; e < e0 + 2; ++e) {
       float a;
@@ -693,7 +795,7 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
       else if (EPI == 1) o[e] = fmaxf(o[e] + a, 0.f);
       else o[e] = o[e] + a;
     }
-    out[2 * I + j] = o;
+    acc[2 * I + j] = o;
   };
   const char* wbase = (const char*)op.W;
 #pragma unroll
@@ -704,11 +806,11 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
     if (I == NB - 1 && issuer) next_layer(nslot);  // slab 0 of the next LINEAR (generic DMA): `op` changes here
     if (PAIRED && grp_b) __syncthreads();
     const float* bias = sl + kSlabRows * Kp + 4 * w.g;
-    out[2 * I] = *(const f32x4*)bias;
-    out[2 * I + 1] = *(const f32x4*)(bias + 16);
+    acc[2 * I] = *(const f32x4*)bias;
+    acc[2 * I + 1] = *(const f32x4*)(bias + 16);
     const char* src = wbase + (size_t)(I + 1) * op.slab_stride * 4;
     const char* bsrc = op.bias != nullptr ? (const char*)(op.bias + (I + 1) * kSlabRows) : (const char*)g_zero128;
-    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, out[2 * I], out[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
+    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, acc[2 * I], acc[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
       if (I > 0 && kb < E) {
 #pragma unroll
         for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
@@ -736,8 +838,10 @@ __device__ __forceinline__ void fast_layer(const Wave& w, float* smem, int& slot
   }
 #pragma unroll
   for (int part = 0; part < 4; ++part) epi_part(NB - 1, part);
+  if constexpr (!BF16) {
 #pragma unroll
-  for (int b = 0; b < 2 * NB; ++b) cur[b] = out[b];
+    for (int b = 0; b < 2 * NB; ++b) cur[b] = out[b];
+  }
 }
 
 // reductions over the 4 lane groups that share a point
@@ -750,21 +854,6 @@ __device__ __forceinline__ float xg_max(float v) {
   return fmaxf(v, __shfl_xor(v, 32));
 }
 
-#ifdef NPF_STAMPS
-// Diagnostic build only (tools/stamp_probe.py): per-phase cycle sums of the slab loop of wave 0
-// of workgroup 0, written to a buffer nothing else reads.
-__device__ unsigned long long g_stamps[16];  // wave 0 (group A), wave 4 (group B, paired variant)
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define NPF_STAMP(i) { const unsigned long long t__ = stamp(); st_sum[i] += t__ - st_last; st_last = t__; }
-#else
-#define NPF_STAMP(i)
-#endif
 
 // EXTRA: the instance that also carries the rarely used LayerNorm ops (transformer attention).  They
 // are kept out of the main instances on purpose: their per-feature index values are loop-invariant,
@@ -782,7 +871,9 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
   constexpr bool kPaired = WAVES == 8;
   constexpr int kSlabFloats = slot_stride(MAXB, BF16, kPaired);  // floats between ring slots
   constexpr int kSlots = ring_instance(BF16, kPaired) ? 4 : (kPaired ? 3 : 2);
-  __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats];
+  constexpr bool kOpsInLds = ring_instance(BF16, kPaired);
+  __shared__ __attribute__((aligned(16))) float smem[kSlots * kSlabFloats + (kOpsInLds ? NPF_MAX_OPS * kOpDwords : 0)];
+  [[maybe_unused]] const float* ops_lds = smem + kSlots * kSlabFloats;
 
   Wave w;
   w.tid = threadIdx.x;
@@ -836,7 +927,25 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
   SlabOp pfs;
   pfs.n_slabs = 0;
   pfs.fast = false;
+  if constexpr (kOpsInLds) {
+    for (int t = w.tid; t < g.n_ops * kOpDwords; t += 64 * WAVES) ((unsigned*)ops_lds)[t] = ((const unsigned*)g.ops)[t];
+    __syncthreads();  // (published before the first seek below; later reads are inline-asm ds_read)
+  }
   auto seek = [&]() {
+    if constexpr (kOpsInLds) {
+      while (pf.op < g.n_ops) {
+        const npf_op_t cand = lds_op(ops_lds, pf.op);
+        if (cand.op == NPF_OP_LINEAR) {
+          pf.nb = 0;
+          pfs = make_slab_op<BF16>(cand, wg_task);
+          slab_fast_setup(pfs, w);
+          return;
+        }
+        ++pf.op;
+      }
+      pf.nb = 0;
+      return;
+    }
     while (pf.op < g.n_ops && g.ops[pf.op].op != NPF_OP_LINEAR) ++pf.op;
     pf.nb = 0;
     if (pf.op < g.n_ops) {
@@ -866,8 +975,11 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
 #endif
   const float* Z = g_zero16;
   for (int ip = 0; ip < g.n_ops; ++ip) {
-    const npf_op_t& o = g.ops[ip];
+    [[maybe_unused]] npf_op_t o_lds;
+    if constexpr (kOpsInLds) o_lds = lds_op(ops_lds, ip);
+    const npf_op_t& o = kOpsInLds ? o_lds : g.ops[ip];
     const int opc = o.op;
+    NPF_STAMP(3)  // back edge of the interpreter loop + fetch of the opcode
     if (opc == NPF_OP_LINEAR) {
       const int KB16 = ((o.i0 + 31) >> 5) * 2, N = o.i1;
       // bf16 instance: LDS row length in floats and number of 32-feature k-steps; the layer's input packed
@@ -909,7 +1021,8 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       bool fast_shape = false;
       if constexpr (FKB > 0)  // (bf16 instance: FKB counts 32-feature steps)
         fast_shape = (BF16 ? o.i0 == 32 * FKB : (KB16 == FKB && o.i0 == 16 * FKB)) && N == 32 * FNB && g.reserved[0] == 0 &&
-                     (grp_b || (pf.op == ip && pf.nb == 1 && pfs.fast)) && !(p16 && !mask);
+                     (grp_b || (pf.op == ip && (pf.nb == 1 || (ring_instance(BF16, kPaired) && pf.nb == 2)) && pfs.fast)) &&
+                     !(p16 && !mask);
       if (fast_shape) {
         if constexpr (FKB > 0) {
           // this layer's slabs 1.. stream inside the pipeline; then the cursor jumps to the next
@@ -924,20 +1037,66 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
             }
           };
           bool done = false;
+          NPF_STAMP(4)  // LINEAR prologue up to the dispatch of the pipelined layer
           if constexpr (ring_instance(BF16, kPaired)) {
             // two slabs in flight: every layer that needs no per-point tensor inside its stages
             const bool plain = (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) == 0;
+            const bool pre2 = pf.nb == 2;  // (the previous ring layer issued this layer's slab 1 as well)
+            // The cursor leaves this layer two stages before its end.  Next LINEAR = a ring layer on the same weight
+            // geometry (everything `lo`, `step`, `slab_stride` depend on): only the two base pointers change, its first
+            // two slabs are issued by this layer's last two stages (returns true).  Anything else: the generic setup,
+            // and slab 0 through `ring_tail` in the last stage.
+            const int tK = o.i0, tN = o.i1, tmode = o.i2, tld = o.i3;
+            auto peek = [&]() __attribute__((always_inline)) -> bool {
+              ++pf.op;
+              pf.nb = 0;
+              while (pf.op < g.n_ops) {
+                const npf_op_t cand = lds_op(ops_lds, pf.op);
+                if (cand.op == NPF_OP_LINEAR) {
+                  const bool same = cand.i0 == tK && cand.i1 == tN && tmode == NPF_W_ROWMAJOR && cand.i2 == NPF_W_ROWMAJOR &&
+                                    cand.i3 == tld && (cand.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) == 0 &&
+                                    (((uintptr_t)cand.p0) & 15) == 0 && (cand.s0 & 3) == 0;
+                  if (same) {
+                    pfs.W = (const float*)cand.p0 + (size_t)wg_task * cand.s0;
+                    pfs.bias = cand.p1 ? (const float*)cand.p1 + (size_t)wg_task * cand.s1 : nullptr;
+                    pf.nb = 2;
+                    return true;
+                  }
+                  pfs = make_slab_op<BF16>(cand, wg_task);
+                  slab_fast_setup(pfs, w);
+                  return false;
+                }
+                ++pf.op;
+              }
+              return false;
+            };
+            auto ring_tail = [&](float* nslot) __attribute__((always_inline)) {
+              if (pf.op < g.n_ops) {
+                SlabDma d = dma_begin(pfs, pf.nb, w, nslot, true);
+                dma_finish(pfs, d, w);
+                advance();
+              }
+            };
+#ifdef NPF_SLIM  // (tools/ring_ablate.py: an instance with nothing in it but the relu ring layer, load and store)
+            if (false) {
+#else
             if (maskb) {
-              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, next_layer);
+              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre2, peek, ring_tail NPF_STAMP_PASS);
               done = true;
+#endif
             } else if (plain && relu) {
-              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, next_layer);
+              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre2, peek, ring_tail NPF_STAMP_PASS);
               done = true;
+#ifndef NPF_SLIM
             } else if (plain) {
-              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, next_layer);
+              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre2, peek, ring_tail NPF_STAMP_PASS);
               done = true;
+#endif
             }
           }
+#ifdef NPF_SLIM
+          done = true;
+#endif
           if (done) {
           } else if (mask && p16) {
             if constexpr (BF16)
@@ -951,8 +1110,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       // queue (out[] shifts down by one slab per iteration), so the loop body exists once
       // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
       // cache) and no dynamically indexed register array is needed.
+#ifndef NPF_SLIM
       [[maybe_unused]] unsigned gmw[2] = {0u, 0u};
       if constexpr (BF16) {
+        // (the queue's old content is never read: defining it here keeps 64 registers from being carried -- and spilled --
+        // around the interpreter loop on behalf of the ring layers, which do not use `out` at all)
+#pragma unroll
+        for (int b = 0; b < kMaxB16; ++b) out[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (maskb && w.valid) {
           gmw[0] = mbits[0];
           if (N > 128) gmw[1] = mbits[128];
@@ -1039,6 +1203,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
 #pragma unroll
           for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv];
         }
+#endif
       }  // generic slab loop
     } else if (opc == NPF_OP_LOAD_PT || opc == NPF_OP_ADD_PT || opc == NPF_OP_MASK_POS || opc == NPF_OP_ROWDOT_PT ||
                opc == NPF_OP_SOFTMAX_BWD) {
@@ -1133,6 +1298,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         for (int b = 0; b < kMaxB16; ++b)
           if (b < FB) *(f32x4*)(t + (4 * b + w.g) * 128) = cur[b];
       }
+#ifndef NPF_SLIM
     } else if (opc == NPF_OP_STORE_TR) {
       // feature-major copy [task][feature][point]: the layout the slab DMA wants when these
       // activations are used as per-task weights with the points as the contraction index
@@ -1329,6 +1495,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       for (int b = 0; b < kMaxB16; ++b)
 #pragma unroll
         for (int s = 0; s < 4; ++s) cur[b][s] = (opc == NPF_OP_RELU) ? fmaxf(cur[b][s], 0.f) : o.f0 * cur[b][s];
+#endif
     }
   }
 #ifdef NPF_STAMPS
