@@ -499,14 +499,10 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
     constexpr int kPf = NPF_BF16_PREFETCH;
     static_assert(kPf >= 1 && kPf <= 3 && KB16S > kPf, "prefetch depth");
     f32x4 fq[kPf + 1][2];
-#ifdef NPF_ABL_NO_LDS  // (tools/ring_ablate.py: timing-only builds, results are garbage)
-#define NPF_RD(set, kbn) asm volatile("" : "=v"(fq[set][0]), "=v"(fq[set][1]) : "v"(addr[(kbn)&3]));
-#else
 #define NPF_RD(set, kbn)                                                                \
   asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"         \
                : "=&v"(fq[set][0]), "=&v"(fq[set][1])                                   \
                : "v"(addr[(kbn)&3]), "n"(((kbn) >> 2) * 256), "n"(((kbn) >> 2) * 256 + kRowBlk));
-#endif
 #pragma unroll
     for (int i = 0; i < kPf; ++i) { NPF_RD(i, i) }
 #pragma unroll
@@ -523,12 +519,8 @@ __device__ __forceinline__ void slab_mfma_side(const float* slot, const Wave& w,
         else if (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fq[c][0]), "+v"(fq[c][1]));
       }
-#ifdef NPF_ABL_NO_MFMA
-      asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(fq[c][0]), "v"(fq[c][1]), "v"(curb[kb]));
-#else
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][0]), curb[kb], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][1]), curb[kb], acc1, 0, 0, 0);
-#endif
       side(kb);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -624,26 +616,41 @@ __device__ __forceinline__ npf_op_t lds_op(const float* ops_lds, int i) {
   }
   npf_op_t o;
   __builtin_memcpy(&o, d, sizeof(o));
+  // (a generic pointer rebuilt from integers makes every access through it a flat_load / flat_store -- slower to issue,
+  // counted on vmcnt AND lgkmcnt, out of order; built as a global pointer first, the accesses are global_*)
+  static_assert(offsetof(npf_op_t, p0) == 32 && offsetof(npf_op_t, p1) == 40 && offsetof(npf_op_t, p2) == 48, "npf_op_t layout");
+  typedef const __attribute__((address_space(1))) void* gvoid_t;
+  o.p0 = (const void*)(gvoid_t)(((unsigned long long)d[9] << 32) | d[8]);
+  o.p1 = (const void*)(gvoid_t)(((unsigned long long)d[11] << 32) | d[10]);
+  o.p2 = (const void*)(gvoid_t)(((unsigned long long)d[13] << 32) | d[12]);
   return o;
 }
 
-// RING (bf16 instance, layers without a per-point PT addend: EPI 1 / 0 on the bias alone, or EPI 3 = mask bits): the
-// four-slot ring two slabs deep.  Stage I multiplies slab I (ring slot s0 + I), and inside its MFMA loop issues the DMA of
-// slab I + 2 (stage 0: slabs 1 and 2); it ends with s_waitcnt vmcnt(5) -- slab I + 1 has landed, the five DMA instructions
-// of slab I + 2 may stay in flight -- and a raw s_barrier.  No register-destination load is issued inside the stages (a
-// wait on one would drag every older DMA with it: vmcnt retires in order), the slab's biases are read by inline-asm
-// ds_read (a C++ LDS load behind an LDS-DMA in flight makes hipcc insert vmcnt(0)).  The last stage hands over exactly
-// like the two-slot form: next layer's slab 0 by the generic DMA code, then a full barrier.  The accumulators are `cur`
-// itself (the input lives on as the packed `curb`): no copy back at the end of the layer.
+// RING (bf16 instance, layers without a per-point PT addend: EPI 1 / 0 on the bias alone, or EPI 3 = mask bits).
+// The layer is ONE software pipeline over its 8 NB k-steps; the slabs stream through a four-slot LDS ring:
+//   * fragment reads run three k-steps ahead of the MFMAs and cross the slab boundary (k-steps 5..7 of stage I read slab
+//     I + 1, whose biases are fetched at k-step 5 straight into the next accumulators): no LDS round trip at a stage start;
+//   * ONE raw s_barrier per stage, in its middle (after k-step 3), preceded by a counted s_waitcnt vmcnt: "slab I + 1 has
+//     landed for every wave, every wave is done with slab I - 1".  Nothing at the stage boundary itself;
+//   * the second half of stage I issues the DMA of stream slab I + 3 (into the slot slab I - 1 has just left): two stages
+//     of flight time before the wait of stage I + 2.  A layer that starts with only its slab 0 in LDS issues slabs 1 and
+//     2 in the first half of stage 0 (and pays one DMA latency there);
+//   * CHAINED hand-over: when the next LINEAR is a ring layer on the same weight geometry (`peek`, at the top of stage
+//     NB - 3), its slabs 0..2 are simply stream slabs NB..NB + 2, issued by the last three stages; that layer then starts
+//     with `pre3` and this one ends without any drain.  Otherwise the last stage hands over through the generic DMA code
+//     (slab 0 of whatever comes next, vmcnt(0), full barrier).
+// No register-destination load is issued inside the stages (a wait on one would drag every older DMA with it: vmcnt
+// retires in order); all LDS reads are inline asm (a C++ LDS load behind an LDS-DMA in flight makes hipcc insert
+// vmcnt(0)).  The accumulators are `cur` itself (the input lives on as the packed `curb`): no copy back.
 template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class Peek, class NextLayer>
 __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB], f32x4 (&)[MAXB],
-                                                const SlabOp& op, const unsigned* mbits, bool pre2, Peek peek,
+                                                const SlabOp& op, const unsigned* mbits, bool pre3, Peek peek,
                                                 NextLayer next_layer NPF_STAMP_ARGS) {
-  static_assert(BF16 && !PAIRED && NB >= 3 && (EPI == 0 || EPI == 1 || EPI == 3), "ring variant");
-  constexpr int Kp = 16 * KB16S;
-  constexpr int NPW = Kp / 32;
-  constexpr int E = KB16S >= 8 ? 4 : (KB16S >= 4 ? 2 : 1);
-  constexpr int PPB = 4 / E;
+  static_assert(BF16 && !PAIRED && NB >= 4 && KB16S == 8 && (EPI == 0 || EPI == 1 || EPI == 3), "ring variant");
+  constexpr int Kp = 16 * KB16S;          // floats per LDS row
+  constexpr int NPW = Kp / 32;            // weight DMA pieces per wave and slab (+ 1 for the biases)
+  constexpr int kRowBlk = 16 * Kp * 4;    // bytes between the two 16-row output blocks of a slab
+  static_assert(NPW == 4, "five DMA instructions per slab over k-steps 4..7");
   unsigned mw[2] = {0u, 0u};
   if constexpr (EPI == 3) {  // the whole layer's mask: two words per lane, first used in stage 1
     mw[0] = mbits[0];
@@ -667,13 +674,9 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
   const int slab_stride = op.slab_stride, step = op.step;
   unsigned lo[2] = {op.lo[0], op.lo[1]};  // (bf16 256-wide rows: 2 rows per piece, the swizzle repeats every 2 pieces)
   const int s0 = slot;
-  NPF_STAMP(5)  // layer setup (pack, mask words)
-  // DMA piece i (i < NPW: weights, i == NPW: the biases) of slab `sb` of the layer (wb, bs) into ring slot (s0 + sb) & 3
+  // DMA piece i (i < NPW: weights, i == NPW: the biases) of slab `sb_src` of the layer (wb, bs) into ring slot (s0 + sb) & 3
   auto issue_of = [&](const char* wb, const float* bs, int sb_src, int sb, int i) __attribute__((always_inline)) {
     float* dst = smem + ((s0 + sb) & 3) * kRingFloats;
-#ifdef NPF_ABL_NO_DMA
-    return;
-#endif
     if (i < NPW) {
       dma16_so(wb + (size_t)sb_src * slab_stride * 4 + (size_t)(i * step) * 4, lo[i & 1], dst + w.wave * 256 + i * (kWaves * 256));
     } else {
@@ -681,79 +684,113 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
       dma4_so(bsrc, (unsigned)(w.lane & 31) * 4u, dst + kSlabRows * Kp);
     }
   };
-  auto issue = [&](int sb, int i) __attribute__((always_inline)) { issue_of(wbase, bias_src, sb, sb, i); };
-  // CHAINED hand-over: when the next LINEAR is a ring layer of the same shape (`peek`, at the top of stage NB - 2), its
-  // slabs 0 and 1 are simply slabs NB and NB + 1 of this stream -- issued inside stages NB - 2 and NB - 1 like any other,
-  // waited for with the same counted vmcnt -- and that layer starts with `pre2`: only slab 2 left to issue in its stage 0.
-  // Otherwise the last stage hands over through the generic DMA code (slab 0 of whatever comes next, full drain).
   bool chain = false;
   const char* nwbase = wbase;
   const float* nbias = bias_src;
+  // LDS addresses: lane part (row p, chunk (4 kb + g) ^ (p & 15): the lane part only depends on kb & 3) + slot base
+  const unsigned lds_ring = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)smem;
+  const int ps = w.p & 15;
+  unsigned lane_off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) lane_off[t] = (unsigned)(w.p * Kp * 4) + (unsigned)(((t ^ (ps >> 2)) << 6) | ((w.g ^ (ps & 3)) << 4));
+  const unsigned bias_off = (unsigned)((kSlabRows * Kp + 4 * w.g) * 4);
+  auto slot_lds = [&](int J) { return lds_ring + (unsigned)(((s0 + J) & 3) * (kRingFloats * 4)); };
+  f32x4 fq[4][2];
+  unsigned a_cur[4], a_nxt[4] = {0u, 0u, 0u, 0u}, b_nxt = 0u;
+#define NPF_RD(set, A, kk)                                                              \
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"         \
+               : "=&v"(fq[set][0]), "=&v"(fq[set][1])                                   \
+               : "v"(A[(kk)&3]), "n"(((kk) >> 2) * 256), "n"(((kk) >> 2) * 256 + kRowBlk));
+#define NPF_BIAS(J, A)                                                                  \
+  asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:64"          \
+               : "=&v"(cur[2 * (J)]), "=&v"(cur[2 * (J) + 1])                           \
+               : "v"(A));
+  {
+    const unsigned base = slot_lds(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_cur[t] = base + lane_off[t];
+    const unsigned b0 = base + bias_off;
+    NPF_BIAS(0, b0)
+    NPF_RD(0, a_cur, 0)
+    NPF_RD(1, a_cur, 1)
+    NPF_RD(2, a_cur, 2)
+  }
+  NPF_STAMP(5)  // layer setup (pack, mask words, first reads)
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
-    const float* sl = smem + ((s0 + I) & 3) * kRingFloats;
-    if (I == NB - 2) {  // `op` changes here
+    if (I == NB - 3) {  // `op` changes here
       chain = peek();
       nwbase = (const char*)op.W;
       nbias = op.bias;
       NPF_STAMP(7)  // peek
     }
     if (I == NB - 1 && !chain) next_layer(smem + ((s0 + NB) & 3) * kRingFloats);  // slab 0 of the next LINEAR
-#ifdef NPF_ABL_BOUNDARY_ONLY  // nothing of the stage but the hand-over to the next layer
-    if (I == NB - 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    continue;
-#endif
-    {  // the slab's biases initialise its two accumulators
-      const unsigned ba = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(sl + kSlabRows * Kp + 4 * w.g);
-      asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(cur[2 * I]), "=&v"(cur[2 * I + 1])
-                   : "v"(ba));
-    }
-    slab_mfma_side<KB16S, MAXB, BF16>(sl, w, cur, curb, cur[2 * I], cur[2 * I + 1], [&](int kb) __attribute__((always_inline)) {
-#ifndef NPF_ABL_NO_EPI
-      if (I > 0 && kb < E) {
+    if (I + 1 < NB) {
+      const unsigned base = slot_lds(I + 1);
 #pragma unroll
-        for (int q = 0; q < PPB; ++q) epi_part(I - 1, kb * PPB + q);
+      for (int t = 0; t < 4; ++t) a_nxt[t] = base + lane_off[t];
+      b_nxt = base + bias_off;
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB16S; ++kb) {
+      // reads three k-steps ahead; the next slab's biases go out just before its first fragments
+      if (kb == 5 && I + 1 < NB) { NPF_BIAS(I + 1, b_nxt) }
+      if (kb + 3 < KB16S) { NPF_RD((kb + 3) & 3, a_cur, kb + 3) }
+      else if (I + 1 < NB) { NPF_RD((kb + 3) & 3, a_nxt, kb + 3 - KB16S) }
+      // wait for this k-step's fragments (and, at k-step 0, the biases, which are older): what may stay in flight are the
+      // reads issued since -- up to three fragment pairs, plus the bias pair of the next slab from k-step 5 on
+      {
+        const int G = KB16S * I + kb, last = KB16S * NB - 1;
+        const int ahead = (last - G) < 3 ? (last - G) : 3;
+        const int cnt = 2 * ahead + ((kb >= 5 && I + 1 < NB) ? 2 : 0);
+        const int c = kb & 3;
+        if (kb == 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fq[c][0]), "+v"(fq[c][1]), "+v"(cur[2 * I]), "+v"(cur[2 * I + 1]) : "n"(cnt));
+        else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[c][0]), "+v"(fq[c][1]) : "n"(cnt));
+        cur[2 * I] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][0]), curb[kb], cur[2 * I], 0, 0, 0);
+        cur[2 * I + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq[c][1]), curb[kb], cur[2 * I + 1], 0, 0, 0);
       }
-#endif
-      if (I == 0) {  // slabs 1 and 2: 2 (NPW + 1) instructions over the KB16S k-steps
-        constexpr int per = (2 * (NPW + 1) + KB16S - 1) / KB16S;
+      // beside the MFMAs, in the second half: the previous slab's epilogue (the mask words, a register load issued at the
+      // top of the layer, are then first needed after a wait that is due anyway) and the DMA of stream slab I + 3
+      if (I > 0 && kb >= 4) epi_part(I - 1, kb - 4);
+      if (I == 0 && kb < 4) {
+        if (!pre3) {  // slabs 1 and 2 of a layer that starts with slab 0 alone: 10 instructions over 4 k-steps
+          constexpr int n0[5] = {0, 3, 6, 8, 10};
 #pragma unroll
-        for (int u = 0; u < per; ++u) {
-          const int n = kb * per + u;
-          if (n < NPW + 1) {
-            if (!pre2) issue(1, n);
-          } else if (n < 2 * (NPW + 1)) issue(2, n - (NPW + 1));
+          for (int n = n0[kb]; n < n0[kb + 1]; ++n) issue_of(wbase, bias_src, 1 + n / (NPW + 1), 1 + n / (NPW + 1), n % (NPW + 1));
         }
-      } else if (I + 2 < NB) {
-        if (kb <= NPW) issue(I + 2, kb);
-      } else {
-        if (chain && kb <= NPW) issue_of(nwbase, nbias, I + 2 - NB, I + 2, kb);
       }
-    });
-    NPF_STAMP(1)  // bias read + MFMA loop with the DMA issue and the previous slab's epilogue inside
-    if (I + 2 < NB || chain) {  // the slab issued in this stage may stay in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
-      NPF_STAMP(0)  // counted DMA wait
-#ifndef NPF_ABL_NO_BAR
-      __builtin_amdgcn_s_barrier();
-#endif
-    } else if (I == NB - 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      NPF_STAMP(0)
-      __syncthreads();  // (vmcnt(0): the next layer's slab 0 has landed)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      NPF_STAMP(0)
-#ifndef NPF_ABL_NO_BAR
-      __builtin_amdgcn_s_barrier();
-#endif
+      if (kb >= 4) {
+#pragma unroll
+        for (int i = kb - 4; i < (kb == 7 ? NPW + 1 : kb - 3); ++i) {
+          if (I + 3 < NB) issue_of(wbase, bias_src, I + 3, I + 3, i);
+          else if (chain) issue_of(nwbase, nbias, I + 3 - NB, I + 3, i);
+        }
+      }
+      if (kb == 3) {
+        NPF_STAMP(1)  // first half of the stage
+        if (I + 2 < NB) {  // slab I + 2 may stay in flight
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
+        } else if (chain) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
+        } else if (I + 1 < NB) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        NPF_STAMP(0)  // counted DMA wait
+        __builtin_amdgcn_s_barrier();
+        NPF_STAMP(2)  // barrier
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    NPF_STAMP(2)  // barrier
+    NPF_STAMP(1)  // second half of the stage
+    if (I == NB - 1 && !chain) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // (vmcnt(0): the next layer's slab 0 has landed)
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_cur[t] = a_nxt[t];
   }
+#undef NPF_RD
+#undef NPF_BIAS
   slot = (s0 + NB) & 3;
 #pragma unroll
   for (int part = 0; part < 4; ++part) epi_part(NB - 1, part);
@@ -1021,7 +1058,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       bool fast_shape = false;
       if constexpr (FKB > 0)  // (bf16 instance: FKB counts 32-feature steps)
         fast_shape = (BF16 ? o.i0 == 32 * FKB : (KB16 == FKB && o.i0 == 16 * FKB)) && N == 32 * FNB && g.reserved[0] == 0 &&
-                     (grp_b || (pf.op == ip && (pf.nb == 1 || (ring_instance(BF16, kPaired) && pf.nb == 2)) && pfs.fast)) &&
+                     (grp_b || (pf.op == ip && (pf.nb == 1 || (ring_instance(BF16, kPaired) && pf.nb == 3)) && pfs.fast)) &&
                      !(p16 && !mask);
       if (fast_shape) {
         if constexpr (FKB > 0) {
@@ -1041,10 +1078,10 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
           if constexpr (ring_instance(BF16, kPaired)) {
             // two slabs in flight: every layer that needs no per-point tensor inside its stages
             const bool plain = (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) == 0;
-            const bool pre2 = pf.nb == 2;  // (the previous ring layer issued this layer's slab 1 as well)
-            // The cursor leaves this layer two stages before its end.  Next LINEAR = a ring layer on the same weight
+            const bool pre3 = pf.nb == 3;  // (the previous ring layer issued this layer's slabs 0..2)
+            // The cursor leaves this layer three stages before its end.  Next LINEAR = a ring layer on the same weight
             // geometry (everything `lo`, `step`, `slab_stride` depend on): only the two base pointers change, its first
-            // two slabs are issued by this layer's last two stages (returns true).  Anything else: the generic setup,
+            // three slabs are issued by this layer's last three stages (returns true).  Anything else: the generic setup,
             // and slab 0 through `ring_tail` in the last stage.
             const int tK = o.i0, tN = o.i1, tmode = o.i2, tld = o.i3;
             auto peek = [&]() __attribute__((always_inline)) -> bool {
@@ -1059,7 +1096,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
                   if (same) {
                     pfs.W = (const float*)cand.p0 + (size_t)wg_task * cand.s0;
                     pfs.bias = cand.p1 ? (const float*)cand.p1 + (size_t)wg_task * cand.s1 : nullptr;
-                    pf.nb = 2;
+                    pf.nb = 3;
                     return true;
                   }
                   pfs = make_slab_op<BF16>(cand, wg_task);
@@ -1077,26 +1114,17 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
                 advance();
               }
             };
-#ifdef NPF_SLIM  // (tools/ring_ablate.py: an instance with nothing in it but the relu ring layer, load and store)
-            if (false) {
-#else
             if (maskb) {
-              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre2, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
-#endif
             } else if (plain && relu) {
-              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre2, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
-#ifndef NPF_SLIM
             } else if (plain) {
-              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre2, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
-#endif
             }
           }
-#ifdef NPF_SLIM
-          done = true;
-#endif
           if (done) {
           } else if (mask && p16) {
             if constexpr (BF16)
@@ -1110,7 +1138,6 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       // queue (out[] shifts down by one slab per iteration), so the loop body exists once
       // (~12 KB of code instead of 8 unrolled copies that overflow the 64 KB instruction
       // cache) and no dynamically indexed register array is needed.
-#ifndef NPF_SLIM
       [[maybe_unused]] unsigned gmw[2] = {0u, 0u};
       if constexpr (BF16) {
         // (the queue's old content is never read: defining it here keeps 64 registers from being carried -- and spilled --
@@ -1203,7 +1230,6 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
 #pragma unroll
           for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv];
         }
-#endif
       }  // generic slab loop
     } else if (opc == NPF_OP_LOAD_PT || opc == NPF_OP_ADD_PT || opc == NPF_OP_MASK_POS || opc == NPF_OP_ROWDOT_PT ||
                opc == NPF_OP_SOFTMAX_BWD) {
@@ -1298,7 +1324,6 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         for (int b = 0; b < kMaxB16; ++b)
           if (b < FB) *(f32x4*)(t + (4 * b + w.g) * 128) = cur[b];
       }
-#ifndef NPF_SLIM
     } else if (opc == NPF_OP_STORE_TR) {
       // feature-major copy [task][feature][point]: the layout the slab DMA wants when these
       // activations are used as per-task weights with the points as the contraction index
@@ -1495,7 +1520,6 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
       for (int b = 0; b < kMaxB16; ++b)
 #pragma unroll
         for (int s = 0; s < 4; ++s) cur[b][s] = (opc == NPF_OP_RELU) ? fmaxf(cur[b][s], 0.f) : o.f0 * cur[b][s];
-#endif
     }
   }
 #ifdef NPF_STAMPS

@@ -26,7 +26,7 @@ lib = _lib.load()
 lib.npf_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 DEV = "cuda:0"
 CH.set_compute_dtype("bf16")
-NAMES = ["counted DMA wait", "bias + MFMA loop (DMA issue, epilogue inside)", "barrier", "loop back edge + opcode fetch",
+NAMES = ["counted DMA wait", "the two halves of the stages (MFMA, DMA issue, epilogue)", "barrier", "loop back edge + opcode fetch",
          "LINEAR prologue (descriptor fields, addresses)", "pack + mask words", "last epilogue", "peek at the next LINEAR"]
 for n_tasks in (16, 1024):
     pts, L = 1024, 8
