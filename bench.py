@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--trgt", type=int, default=None, help="target points per task (overrides the preset)")
     ap.add_argument("--r", type=int, default=None, help="feature width (overrides the preset)")
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--attention", default="scaledot", choices=["scaledot", "transformer"],
+                    help="cross attention of the model (BASELINE configs: scaledot; transformer = what the reference's "
+                         "shipped checkpoints use, an example workload, not a BASELINE config)")
     ap.add_argument("--dtype", default=None, choices=["fp32", "bf16"],
                     help="fp32 | bf16 (bf16 MFMA products in the MLP stacks, attention and weight gradients; fp32 accumulation)")
     ap.add_argument("--no-graph", action="store_true",
@@ -85,7 +88,8 @@ def parse_args(argv=None):
         ap.error("the decode-only workload is fp32")
     if args.config in ("c2",) and args.dtype != "fp32":
         ap.error("config c2 is fp32 (bf16 is c3)")
-    args.preset = (args.batch is None and args.trgt is None and args.r is None and args.ctx == 256 and args.layers == 4)
+    args.preset = (args.batch is None and args.trgt is None and args.r is None and args.ctx == 256 and args.layers == 4
+                   and args.attention == "scaledot")
     args.batch = preset["batch"] if args.batch is None else args.batch
     args.trgt = preset["trgt"] if args.trgt is None else args.trgt
     args.r = preset["r"] if args.r is None else args.r
@@ -253,7 +257,7 @@ def cpu_baseline_decode(r: int, L: int, T: int, budget_s: float = 10.0):
 # ---------------------------------------------------------------------------------------
 # the measured workloads
 # ---------------------------------------------------------------------------------------
-def build_model(kind: str, r: int, L: int, device):
+def build_model(kind: str, r: int, L: int, device, attention: str = "scaledot"):
     import torch
     import npf_gwwaveform_amd as A
 
@@ -265,9 +269,9 @@ def build_model(kind: str, r: int, L: int, device):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         if kind == "attncnp":
-            m, crit = A.AttnCNP(1, 2, attention="scaledot", **kw), A.CNPFLoss()
+            m, crit = A.AttnCNP(1, 2, attention=attention, **kw), A.CNPFLoss()
         else:
-            m = A.AttnLNP(1, 2, attention="scaledot", is_q_zCct=True, n_z_samples_train=1, n_z_samples_test=1, **kw)
+            m = A.AttnLNP(1, 2, attention=attention, is_q_zCct=True, n_z_samples_train=1, n_z_samples_test=1, **kw)
             crit = A.ELBOLossLNPF()
     return m.to(device), crit
 
@@ -432,7 +436,7 @@ def main_train(args, rank, world, dev, sync, rehearsal):
         import npf_gwwaveform_amd as A
 
         A.set_compute_dtype("bf16")
-    model, crit = build_model(args.model, args.r, args.layers, dev)
+    model, crit = build_model(args.model, args.r, args.layers, dev, args.attention)
     n_params = sum(p.numel() for p in model.parameters())
     use_graph = world == 1 and not args.no_graph
     trainer = Trainer(model, crit, lr=1e-3, world=world, use_graph=use_graph)
@@ -482,7 +486,7 @@ def main_train(args, rank, world, dev, sync, rehearsal):
             "dtype": "f32" if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
-                "workload": f"BASELINE config {args.config_number}: {model_name} scaledot, r={args.r}, {args.layers}-layer "
+                "workload": f"{'BASELINE config ' + str(args.config_number) if args.attention == 'scaledot' else 'example (not a BASELINE config)'}: {model_name} {args.attention}, r={args.r}, {args.layers}-layer "
                             f"xy-encoder/decoder, {C} context / {T} target points, {B} tasks per GPU ({B * world} global), "
                             f"{args.dtype} train step (fwd+loss+bwd+allreduce+Adam)",
                 "name": args.config, "tasks_per_gpu": B, "global_tasks": B * world, "context_points": C, "target_points": T,

@@ -116,6 +116,10 @@ enum npf_wmode {
 #define NPF_F_MASK_BITS 32u /* bf16 mode only: like MASK_PT with the mask as bits, p2 = PTM tensor (NPF_OP_STORE_MASK)   */
 #define NPF_F_ADD_RM 8u  /* like ADD_PT with a row-major addend p2 [task][pt][i1] (i1 % 32 == 0): module-
                             boundary tensors enter without a layout pass (inference paths)            */
+#define NPF_F_STORE_IN 64u /* bf16 mode only. LINEAR: PT tensor p3 <- the layer's INPUT (i0 features), exactly what NPF_OP_STORE_PT in
+                              front of the layer would store; the pipelined layers spread the stores over their stages
+                              instead of bursting them between two layers                                       */
+#define NPF_F_STORE_P16 128u /* bf16 mode only, with NPF_F_STORE_IN: p3 is a PT16 tensor (see NPF_F_P16)                */
 
 typedef struct npf_op {
   int32_t op;        /* npf_opcode                                                              */
@@ -133,6 +137,7 @@ typedef struct npf_op {
   const void *p2;    /* LINEAR: PT32 addend or NULL                                             */
   int64_t s0;        /* LINEAR: per-task stride of W in floats (0 = shared)                     */
   int64_t s1;        /* LINEAR: per-task stride of bias in floats (0 = shared)                  */
+  void *p3;          /* LINEAR with NPF_F_STORE_IN: destination of the input store              */
 } npf_op_t;
 
 typedef struct npf_program {

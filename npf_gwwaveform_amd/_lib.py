@@ -25,7 +25,7 @@ OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFT
     OP_STORE_MASK, OP_MASK_BITS = range(22)
 # weight modes (enum npf_wmode)
 W_ROWMAJOR, W_PT_ROWS, W_PT_COLS = range(3)
-F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16, F_MASK_BITS = 1, 2, 4, 8, 16, 32
+F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16, F_MASK_BITS, F_STORE_IN, F_STORE_P16 = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class NpfOp(C.Structure):
@@ -33,7 +33,7 @@ class NpfOp(C.Structure):
         ("op", C.c_int32), ("i0", C.c_int32), ("i1", C.c_int32), ("i2", C.c_int32), ("i3", C.c_int32),
         ("flags", C.c_uint32), ("f0", C.c_float), ("i4", C.c_int32),
         ("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p),
-        ("s0", C.c_int64), ("s1", C.c_int64),
+        ("s0", C.c_int64), ("s1", C.c_int64), ("p3", C.c_void_p),
     ]
 
 
@@ -62,7 +62,7 @@ class NpfWprepJob(C.Structure):
 
 
 NPF_MAX_WPREP_JOBS = 32
-assert C.sizeof(NpfOp) == 72 and C.sizeof(NpfProgram) == 32 + 72 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 72 and C.sizeof(NpfWprepJob) == 32
+assert C.sizeof(NpfOp) == 80 and C.sizeof(NpfProgram) == 32 + 80 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 72 and C.sizeof(NpfWprepJob) == 32
 
 # name -> (restype, argtypes); must list every symbol declared in include/npf_hip.h
 _i32, _i64, _p = C.c_int32, C.c_int64, C.c_void_p

@@ -30,6 +30,7 @@ DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microben
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 PT16_INTERNAL = os.environ.get("NPF_NO_PT16", "0") != "1"  # bf16 mode: backward-only tensors as bf16 tiles (debug switch)
 MASK_BITS = os.environ.get("NPF_NO_MASK_BITS", "0") != "1"  # bf16 mode: ReLU masks of the backward pass as bits (debug switch)
+FUSE_STORES = os.environ.get("NPF_NO_FUSED_STORE", "0") != "1"  # bf16 mode: STORE_PT + LINEAR -> LINEAR | F_STORE_IN (debug switch)
 
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
@@ -262,9 +263,17 @@ class Program:
         self.bf16 = True
         p_add, fl_add = self._pt(addend) if addend is not None else (None, 0)  # (fp32 PT32 or PT16)
         flags = (L.F_RELU if relu else 0) | ((L.F_ADD_PT | fl_add) if addend is not None else 0)
+        # a store of the layer's input right in front of it rides inside the layer (NPF_F_STORE_IN): the pipelined
+        # layers spread it over their stages instead of bursting 8 store instructions per wave between two layers
+        p3 = None
+        last = self.ops[-1] if self.ops else None
+        if FUSE_STORES and last is not None and last.op == L.OP_STORE_PT and last.i0 == pad32(K):
+            self.ops.pop()
+            p3 = last.p0
+            flags |= L.F_STORE_IN | (L.F_STORE_P16 if last.flags & L.F_P16 else 0)
         self.keep.append(W_img)
         self._op(op=L.OP_LINEAR, i0=K, i1=N, i2=L.W_ROWMAJOR, i3=pad32(K) // 2, flags=flags, i4=addend_modulus,
-                 p0=W_img.data_ptr(), p1=self._p(bias), p2=p_add,
+                 p0=W_img.data_ptr(), p1=self._p(bias), p2=p_add, p3=p3,
                  s0=(W_img.shape[1] * pad32(K) // 2 if per_task else 0), s1=b_task_stride)
 
     def store_wb(self, img, F):
@@ -309,6 +318,8 @@ class Program:
                     per_pt += (2 if o.flags & L.F_P16 else 4) * pad32(o.i1)
                 if o.flags & L.F_MASK_BITS:
                     per_pt += 16 * ((pad32(o.i1) + 127) // 128)
+                if o.flags & L.F_STORE_IN:
+                    per_pt += (2 if o.flags & L.F_STORE_P16 else 4) * pad32(o.i0)
                 per_task = o.i2 != L.W_ROWMAJOR or o.s0 != 0
                 fixed += 4 * o.i0 * o.i1 * (self.n_tasks if per_task else 1)
         return per_pt * pts + fixed

@@ -597,20 +597,21 @@ __device__ __forceinline__ unsigned long long stamp() {
 // load cannot be issued ahead, it shares lgkmcnt with the stream of LDS fragment waits.  So the workgroup copies the table
 // to LDS once (vector loads, one round trip), and an op is fetched by nine broadcast ds_read_b64 + readfirstlane.
 constexpr int kOpDwords = sizeof(npf_op_t) / 4;
-static_assert(sizeof(npf_op_t) == 72, "npf_op_t layout");
+static_assert(sizeof(npf_op_t) == 80, "npf_op_t layout");
 __device__ __forceinline__ npf_op_t lds_op(const float* ops_lds, int i) {
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(ops_lds + i * kOpDwords);
-  u32x2_t r[9];
+  u32x2_t r[10];
   asm volatile(
-      "ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\t"
-      "ds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\tds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56\n\t"
-      "ds_read_b64 %8, %9 offset:64\n\ts_waitcnt lgkmcnt(0)"
-      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8])
+      "ds_read_b64 %0, %10\n\tds_read_b64 %1, %10 offset:8\n\tds_read_b64 %2, %10 offset:16\n\tds_read_b64 %3, %10 offset:24\n\t"
+      "ds_read_b64 %4, %10 offset:32\n\tds_read_b64 %5, %10 offset:40\n\tds_read_b64 %6, %10 offset:48\n\tds_read_b64 %7, %10 offset:56\n\t"
+      "ds_read_b64 %8, %10 offset:64\n\tds_read_b64 %9, %10 offset:72\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+        "=&v"(r[9])
       : "v"(a));
   unsigned d[kOpDwords];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+  for (int k = 0; k < 10; ++k) {
     d[2 * k] = (unsigned)__builtin_amdgcn_readfirstlane((int)r[k][0]);
     d[2 * k + 1] = (unsigned)__builtin_amdgcn_readfirstlane((int)r[k][1]);
   }
@@ -618,11 +619,14 @@ __device__ __forceinline__ npf_op_t lds_op(const float* ops_lds, int i) {
   __builtin_memcpy(&o, d, sizeof(o));
   // (a generic pointer rebuilt from integers makes every access through it a flat_load / flat_store -- slower to issue,
   // counted on vmcnt AND lgkmcnt, out of order; built as a global pointer first, the accesses are global_*)
-  static_assert(offsetof(npf_op_t, p0) == 32 && offsetof(npf_op_t, p1) == 40 && offsetof(npf_op_t, p2) == 48, "npf_op_t layout");
+  static_assert(offsetof(npf_op_t, p0) == 32 && offsetof(npf_op_t, p1) == 40 && offsetof(npf_op_t, p2) == 48 &&
+                offsetof(npf_op_t, p3) == 72, "npf_op_t layout");
   typedef const __attribute__((address_space(1))) void* gvoid_t;
+  typedef __attribute__((address_space(1))) void* gvoid_w_t;
   o.p0 = (const void*)(gvoid_t)(((unsigned long long)d[9] << 32) | d[8]);
   o.p1 = (const void*)(gvoid_t)(((unsigned long long)d[11] << 32) | d[10]);
   o.p2 = (const void*)(gvoid_t)(((unsigned long long)d[13] << 32) | d[12]);
+  o.p3 = (void*)(gvoid_w_t)(((unsigned long long)d[19] << 32) | d[18]);
   return o;
 }
 
@@ -638,14 +642,16 @@ __device__ __forceinline__ npf_op_t lds_op(const float* ops_lds, int i) {
 //   * CHAINED hand-over: when the next LINEAR is a ring layer on the same weight geometry (`peek`, at the top of stage
 //     NB - 3), its slabs 0..2 are simply stream slabs NB..NB + 2, issued by the last three stages; that layer then starts
 //     with `pre3` and this one ends without any drain.  Otherwise the last stage hands over through the generic DMA code
-//     (slab 0 of whatever comes next, vmcnt(0), full barrier).
+//     (slab 0 of whatever comes next, vmcnt(0), full barrier);
+//   * NPF_F_STORE_IN (`st16`): the PT16 copy of the layer's input IS the packed `curb`: stage I stores chunk I at k-step 4,
+//     in front of that stage's DMA, and the counted waits of the stages >= 1 allow for it.
 // No register-destination load is issued inside the stages (a wait on one would drag every older DMA with it: vmcnt
 // retires in order); all LDS reads are inline asm (a C++ LDS load behind an LDS-DMA in flight makes hipcc insert
 // vmcnt(0)).  The accumulators are `cur` itself (the input lives on as the packed `curb`): no copy back.
 template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class Peek, class NextLayer>
 __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB], f32x4 (&)[MAXB],
-                                                const SlabOp& op, const unsigned* mbits, bool pre3, Peek peek,
-                                                NextLayer next_layer NPF_STAMP_ARGS) {
+                                                const SlabOp& op, const unsigned* mbits, const unsigned short* st16, bool pre3,
+                                                Peek peek, NextLayer next_layer NPF_STAMP_ARGS) {
   static_assert(BF16 && !PAIRED && NB >= 4 && KB16S == 8 && (EPI == 0 || EPI == 1 || EPI == 3), "ring variant");
   constexpr int Kp = 16 * KB16S;          // floats per LDS row
   constexpr int NPW = Kp / 32;            // weight DMA pieces per wave and slab (+ 1 for the biases)
@@ -759,6 +765,7 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
           for (int n = n0[kb]; n < n0[kb + 1]; ++n) issue_of(wbase, bias_src, 1 + n / (NPW + 1), 1 + n / (NPW + 1), n % (NPW + 1));
         }
       }
+      if (kb == 4 && st16 != nullptr) *(bf16x8*)(st16 + 1024 * I) = curb[I];  // NPF_F_STORE_IN: chunk I of the PT16 copy of the input
       if (kb >= 4) {
 #pragma unroll
         for (int i = kb - 4; i < (kb == 7 ? NPW + 1 : kb - 3); ++i) {
@@ -768,10 +775,9 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
       }
       if (kb == 3) {
         NPF_STAMP(1)  // first half of the stage
-        if (I + 2 < NB) {  // slab I + 2 may stay in flight
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
-        } else if (chain) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
+        if (I + 2 < NB || chain) {  // slab I + 2 may stay in flight -- and the input store of stage I - 1 issued in front of it
+          if (I >= 1 && st16 != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 2) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + 1) : "memory");
         } else if (I + 1 < NB) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1060,6 +1066,30 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
         fast_shape = (BF16 ? o.i0 == 32 * FKB : (KB16 == FKB && o.i0 == 16 * FKB)) && N == 32 * FNB && g.reserved[0] == 0 &&
                      (grp_b || (pf.op == ip && (pf.nb == 1 || (ring_instance(BF16, kPaired) && pf.nb == 3)) && pfs.fast)) &&
                      !(p16 && !mask);
+      // NPF_F_STORE_IN (bf16 programs): a ring layer stores its packed input itself, chunk by chunk; everything else
+      // stores it here, before the layer, exactly like NPF_OP_STORE_PT
+      [[maybe_unused]] const bool ring_plain = (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) == 0;
+      [[maybe_unused]] const unsigned short* st16 = nullptr;
+      if constexpr (BF16) {
+        if ((o.flags & NPF_F_STORE_IN) && w.valid) {
+          const int Fin = ((o.i0 + 31) >> 5) * 32;
+          if (o.flags & NPF_F_STORE_P16) {
+            unsigned short* t16 = (unsigned short*)pt16_lane(o.p3, g, w, Fin, 0);
+            if (ring_instance(BF16, kPaired) && fast_shape && (maskb || ring_plain)) {
+              st16 = t16;
+            } else {
+#pragma unroll
+              for (int st = 0; st < kMaxB16 / 2; ++st)
+                if (32 * st < Fin) *(bf16x8*)(t16 + 1024 * st) = curb[st];
+            }
+          } else {
+            float* t = (float*)pt_lane(o.p3, g, w, Fin, 0);
+#pragma unroll
+            for (int b = 0; b < kMaxB16; ++b)
+              if (16 * b < Fin) *(f32x4*)(t + (4 * b + w.g) * 128) = cur[b];
+          }
+        }
+      }
       if (fast_shape) {
         if constexpr (FKB > 0) {
           // this layer's slabs 1.. stream inside the pipeline; then the cursor jumps to the next
@@ -1077,7 +1107,7 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
           NPF_STAMP(4)  // LINEAR prologue up to the dispatch of the pipelined layer
           if constexpr (ring_instance(BF16, kPaired)) {
             // two slabs in flight: every layer that needs no per-point tensor inside its stages
-            const bool plain = (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM)) == 0;
+            const bool plain = ring_plain;
             const bool pre3 = pf.nb == 3;  // (the previous ring layer issued this layer's slabs 0..2)
             // The cursor leaves this layer three stages before its end.  Next LINEAR = a ring layer on the same weight
             // geometry (everything `lo`, `step`, `slab_stride` depend on): only the two base pointers change, its first
@@ -1115,13 +1145,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
               }
             };
             if (maskb) {
-              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre3, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
             } else if (plain && relu) {
-              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre3, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
             } else if (plain) {
-              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, pre3, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
             }
           }
@@ -1562,6 +1592,9 @@ static int validate(const npf_program_t* g) {
           if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) || !o.p2 || (((uintptr_t)o.p2) & 15) || (o.i1 & 31)) return NPF_EINVAL;
         }
         if (o.s1 != 0 && !g->wg_per_task) return NPF_EINVAL;
+        if (o.flags & (NPF_F_STORE_IN | NPF_F_STORE_P16)) {  // (bf16 programs only: see DESIGN.md 9 for the fp32 attempt)
+          if (g->reserved[2] != 1 || !(o.flags & NPF_F_STORE_IN) || !o.p3 || (((uintptr_t)o.p3) & 15)) return NPF_EINVAL;
+        }
         break;
       case NPF_OP_LOAD_PT:
       case NPF_OP_STORE_PT:

@@ -40,8 +40,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_abi_struct_sizes_match_header():
     from npf_gwwaveform_amd import _lib
 
-    assert ctypes.sizeof(_lib.NpfOp) == 72
-    assert ctypes.sizeof(_lib.NpfProgram) == 32 + 72 * 40
+    assert ctypes.sizeof(_lib.NpfOp) == 80
+    assert ctypes.sizeof(_lib.NpfProgram) == 32 + 80 * 40
     assert ctypes.sizeof(_lib.NpfWgradJob) == 72
     hdr = open(os.path.join(ROOT, "include", "npf_hip.h")).read()
     assert f"#define NPF_MAX_OPS {_lib.NPF_MAX_OPS}" in hdr
