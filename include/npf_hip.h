@@ -119,6 +119,8 @@ enum npf_wmode {
 #define NPF_F_STORE_IN 64u /* bf16 mode only. LINEAR: PT tensor p3 <- the layer's INPUT (i0 features), exactly what NPF_OP_STORE_PT in
                               front of the layer would store; the pipelined layers spread the stores over their stages
                               instead of bursting them between two layers                                       */
+#define NPF_F_STORE_BITS 256u /* bf16 mode only. LINEAR with NPF_F_RELU and no addend / mask: PTM tensor p2 <- (output > 0) as
+                                 bits, exactly what NPF_OP_STORE_MASK behind the layer would store (i1 <= 256)             */
 #define NPF_F_STORE_P16 128u /* bf16 mode only, with NPF_F_STORE_IN: p3 is a PT16 tensor (see NPF_F_P16)                */
 
 typedef struct npf_op {

@@ -25,7 +25,7 @@ OP_END, OP_LOAD_PT, OP_STORE_PT, OP_LOAD_ROWS, OP_STORE_ROWS, OP_LINEAR, OP_SOFT
     OP_STORE_MASK, OP_MASK_BITS = range(22)
 # weight modes (enum npf_wmode)
 W_ROWMAJOR, W_PT_ROWS, W_PT_COLS = range(3)
-F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16, F_MASK_BITS, F_STORE_IN, F_STORE_P16 = 1, 2, 4, 8, 16, 32, 64, 128
+F_RELU, F_ADD_PT, F_MASK_PT, F_ADD_RM, F_P16, F_MASK_BITS, F_STORE_IN, F_STORE_P16, F_STORE_BITS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class NpfOp(C.Structure):

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -30,6 +31,7 @@ DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microben
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 PT16_INTERNAL = os.environ.get("NPF_NO_PT16", "0") != "1"  # bf16 mode: backward-only tensors as bf16 tiles (debug switch)
 MASK_BITS = os.environ.get("NPF_NO_MASK_BITS", "0") != "1"  # bf16 mode: ReLU masks of the backward pass as bits (debug switch)
+DUMP_PROGRAMS = os.environ.get("NPF_DUMP_PROGRAMS", "0") == "1"
 FUSE_STORES = os.environ.get("NPF_NO_FUSED_STORE", "0") != "1"  # bf16 mode: STORE_PT + LINEAR -> LINEAR | F_STORE_IN (debug switch)
 
 
@@ -194,6 +196,13 @@ class Program:
         """PTM tensor ``m`` <- (cur > 0) as bits (bf16 programs)."""
         self.bf16 = True
         self.keep.append(m)
+        last = self.ops[-1] if self.ops else None
+        if (FUSE_STORES and last is not None and last.op == L.OP_LINEAR and pad32(last.i1) == pad32(F) and F <= 256
+                and (last.flags & L.F_RELU) and last.p2 is None
+                and not (last.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_ADD_RM | L.F_MASK_BITS | L.F_STORE_BITS))):
+            last.flags |= L.F_STORE_BITS  # the layer's epilogue shifts the bits in as it goes (NPF_F_STORE_BITS)
+            last.p2 = m.data_ptr()
+            return
         self._op(op=L.OP_STORE_MASK, i0=pad32(F), p0=m.data_ptr())
 
     def mask_bits(self, m, F):
@@ -316,7 +325,7 @@ class Program:
             elif o.op == L.OP_LINEAR:
                 if o.flags & (L.F_ADD_PT | L.F_MASK_PT | L.F_ADD_RM):
                     per_pt += (2 if o.flags & L.F_P16 else 4) * pad32(o.i1)
-                if o.flags & L.F_MASK_BITS:
+                if o.flags & (L.F_MASK_BITS | L.F_STORE_BITS):
                     per_pt += 16 * ((pad32(o.i1) + 127) // 128)
                 if o.flags & L.F_STORE_IN:
                     per_pt += (2 if o.flags & L.F_STORE_P16 else 4) * pad32(o.i0)
@@ -336,7 +345,21 @@ class Program:
         else:
             self._launch()
 
+    def describe(self) -> str:
+        """One line per op (debugging aid: NPF_DUMP_PROGRAMS=1 prints it at every launch)."""
+        names = {v: k[3:] for k, v in vars(L).items() if k.startswith("OP_")}
+        flag_names = [(L.F_RELU, "relu"), (L.F_ADD_PT, "add_pt"), (L.F_MASK_PT, "mask_pt"), (L.F_ADD_RM, "add_rm"),
+                      (L.F_P16, "p16"), (L.F_MASK_BITS, "mask_bits"), (L.F_STORE_IN, "store_in"),
+                      (L.F_STORE_P16, "store_p16"), (L.F_STORE_BITS, "store_bits")]
+        lines = [f"program: {self.n_tasks} tasks x {self.pts} points, wg_per_task={int(self.wg_per_task)}, bf16={int(self.bf16)}"]
+        for o in self.ops:
+            fl = "|".join(n for b, n in flag_names if o.flags & b)
+            lines.append(f"  {names.get(o.op, o.op):12s} i0={o.i0:4d} i1={o.i1:4d} i2={o.i2} i4={o.i4} {fl}")
+        return "\n".join(lines)
+
     def _launch(self) -> None:
+        if DUMP_PROGRAMS:
+            print(self.describe(), file=sys.stderr)
         prog = L.NpfProgram()
         prog.n_ops = len(self.ops)
         prog.n_tasks, prog.pts_per_task, prog.tiles_per_task = self.n_tasks, self.pts, tiles_of(self.pts)

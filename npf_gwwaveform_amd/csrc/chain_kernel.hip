@@ -650,8 +650,8 @@ __device__ __forceinline__ npf_op_t lds_op(const float* ops_lds, int i) {
 // vmcnt(0)).  The accumulators are `cur` itself (the input lives on as the packed `curb`): no copy back.
 template <int EPI, int KB16S, int NB, int MAXB, bool PAIRED, bool BF16, bool P16, class Peek, class NextLayer>
 __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int& slot, f32x4 (&cur)[MAXB], f32x4 (&)[MAXB],
-                                                const SlabOp& op, const unsigned* mbits, const unsigned short* st16, bool pre3,
-                                                Peek peek, NextLayer next_layer NPF_STAMP_ARGS) {
+                                                const SlabOp& op, const unsigned* mbits, const unsigned short* st16,
+                                                unsigned* mst, bool pre3, Peek peek, NextLayer next_layer NPF_STAMP_ARGS) {
   static_assert(BF16 && !PAIRED && NB >= 4 && KB16S == 8 && (EPI == 0 || EPI == 1 || EPI == 3), "ring variant");
   constexpr int Kp = 16 * KB16S;          // floats per LDS row
   constexpr int NPW = Kp / 32;            // weight DMA pieces per wave and slab (+ 1 for the biases)
@@ -665,6 +665,7 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
   bf16x8 curb[MAXB / 2] = {};
 #pragma unroll
   for (int st = 0; st < KB16S; ++st) curb[st] = pack_bf16(cur[2 * st], cur[2 * st + 1]);
+  unsigned mo[2] = {0u, 0u};  // NPF_F_STORE_BITS (`mst`): the output's ReLU bits, shifted in as the epilogue goes (PTM order)
   auto epi_part = [&](int I, int part) __attribute__((always_inline)) {
     const int j = part >> 1, e0 = (part & 1) * 2;
     f32x4 o = cur[2 * I + j];
@@ -672,6 +673,13 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
     for (int e = e0; e < e0 + 2; ++e) {
       if constexpr (EPI == 3) o[e] = mask_bit(mw[(2 * I + j) >> 3], (2 * I + j) & 7, e) ? o[e] : 0.f;
       else if constexpr (EPI == 1) o[e] = fmaxf(o[e], 0.f);
+    }
+    if constexpr (EPI == 1) {
+      if (mst != nullptr) {
+#pragma unroll
+        for (int e = e0; e < e0 + 2; ++e)
+          asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mo[(2 * I + j) >> 3]) : "v"(o[e]) : "vcc");
+      }
     }
     cur[2 * I + j] = o;
   };
@@ -800,6 +808,12 @@ __device__ __forceinline__ void fast_layer_ring(const Wave& w, float* smem, int&
   slot = (s0 + NB) & 3;
 #pragma unroll
   for (int part = 0; part < 4; ++part) epi_part(NB - 1, part);
+  if constexpr (EPI == 1) {
+    if (mst != nullptr) {
+      mst[0] = mo[0];
+      if constexpr (NB > 4) mst[128] = mo[1];
+    }
+  }
   NPF_STAMP(6)  // last epilogue
 }
 
@@ -1090,6 +1104,17 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
           }
         }
       }
+      // NPF_F_STORE_BITS (bf16 programs): the ReLU ring layer shifts the bits in inside its epilogue; everything else
+      // runs the NPF_OP_STORE_MASK code behind the layer
+      [[maybe_unused]] unsigned* mst = nullptr;
+      [[maybe_unused]] bool mst_after = false;
+      if constexpr (BF16) {
+        if ((o.flags & NPF_F_STORE_BITS) && w.valid) {
+          const size_t tile = (size_t)w.task * g.tiles_per_task + w.tile_in_task;
+          mst = (unsigned*)o.p2 + (tile * ((N + 127) >> 7) * 4 + w.g) * 32 + 16 * w.half + w.p;
+          mst_after = !(ring_instance(BF16, kPaired) && fast_shape && ring_plain && relu && !maskb);
+        }
+      }
       if (fast_shape) {
         if constexpr (FKB > 0) {
           // this layer's slabs 1.. stream inside the pipeline; then the cursor jumps to the next
@@ -1145,13 +1170,13 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
               }
             };
             if (maskb) {
-              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, pre3, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<3, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, nullptr, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
             } else if (plain && relu) {
-              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, pre3, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<1, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, mst, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
             } else if (plain) {
-              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, pre3, peek, ring_tail NPF_STAMP_PASS);
+              fast_layer_ring<0, FKB, FNB, MAXB, kPaired, BF16, false>(w, smem, slot, cur, out, pfs, mbits, st16, nullptr, pre3, peek, ring_tail NPF_STAMP_PASS);
               done = true;
             }
           }
@@ -1261,6 +1286,24 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
           for (int b = 0; b < kBlk * nbv; ++b) cur[b] = out[b + kMaxB16 - kBlk * nbv];
         }
       }  // generic slab loop
+      if constexpr (BF16) {
+        if (mst_after) {  // NPF_F_STORE_BITS on a layer that did not go through the ReLU ring
+#pragma unroll
+          for (int q = 0; q < kMaxB16 / 8; ++q) {
+            if (128 * q < N) {
+              unsigned word = 0u;
+#pragma unroll
+              for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float x = (16 * (8 * q + bb) < N) ? cur[8 * q + bb][e] : 0.f;
+                  asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(x) : "vcc");
+                }
+              mst[128 * q] = word;
+            }
+          }
+        }
+      }
     } else if (opc == NPF_OP_LOAD_PT || opc == NPF_OP_ADD_PT || opc == NPF_OP_MASK_POS || opc == NPF_OP_ROWDOT_PT ||
                opc == NPF_OP_SOFTMAX_BWD) {
       const int FB = o.i0 >> 4;
@@ -1592,6 +1635,11 @@ static int validate(const npf_program_t* g) {
           if ((o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT)) || !o.p2 || (((uintptr_t)o.p2) & 15) || (o.i1 & 31)) return NPF_EINVAL;
         }
         if (o.s1 != 0 && !g->wg_per_task) return NPF_EINVAL;
+        if (o.flags & NPF_F_STORE_BITS) {  // (bf16 programs only)
+          if (g->reserved[2] != 1 || !(o.flags & NPF_F_RELU) || o.i1 > 256 || !o.p2 || (((uintptr_t)o.p2) & 3) ||
+              (o.flags & (NPF_F_ADD_PT | NPF_F_MASK_PT | NPF_F_ADD_RM | NPF_F_MASK_BITS)))
+            return NPF_EINVAL;
+        }
         if (o.flags & (NPF_F_STORE_IN | NPF_F_STORE_P16)) {  // (bf16 programs only: see DESIGN.md 9 for the fp32 attempt)
           if (g->reserved[2] != 1 || !(o.flags & NPF_F_STORE_IN) || !o.p3 || (((uintptr_t)o.p3) & 15)) return NPF_EINVAL;
         }

@@ -43,6 +43,7 @@ __device__ __forceinline__ void wg_dma16(const float* src, float* lds_dst_wave_u
 // read (16 quad rows x 4 consecutive points per ds_read_b128) is then bank-conflict free and
 // a 1 KiB LDS-DMA piece (2 rows) lands linearly with the swizzle applied to its source address.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   };
 
   __syncthreads();
-  if (t0 < t1) step_dma(t0, lds);
+  if (t0 < t1 && !(BF16 && dual)) step_dma(t0, lds);
 
   // fragment addresses: chunk (4 s + g) ^ i of quad row (base + i); with s = 4 m + t the lane
   // part only depends on t (4 address registers per operand, m goes to the immediate offset)
@@ -227,6 +228,56 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
     }
   }
 
+  // bf16 variant, both operands PT16 (every MLP layer of a bf16 step): FOUR slots of one tile pair (16 + 16 KiB) each,
+  // three tiles in flight while the fourth is multiplied.  A tile is retired by a COUNTED s_waitcnt vmcnt (each wave
+  // issues `pw` <= 2 DMA instructions per tile: the two younger tiles may stay in flight) and a raw s_barrier; the DMA
+  // of tile n + 3 goes into the slot tile n - 1 has just left.  With two tiles per barrier and a full drain at every
+  // barrier (the loop below) the launch sat at ~4.3 TB/s: 64 KiB in flight per CU, none across the barrier.
+  if constexpr (BF16) {
+    if (dual) {
+      const int pw = (wave < (Np >> zsh) ? 1 : 0) + (wave < (Kp >> ash) ? 1 : 0);
+      auto slot_of = [&](long n) { return lds + ((n >> 1) & 1) * 2 * kOp + (n & 1) * (kOp / 2); };
+      const long n_tiles = t0 < t1 ? (t1 - t0 + tstride - 1) / tstride : 0;
+      for (long n = 0; n < 3 && n < n_tiles; ++n) tile_dma(t0 + n * tstride, slot_of(n));
+      for (long n = 0; n < n_tiles; ++n) {
+        const long younger = (n_tiles - 1 - n) < 2 ? (n_tiles - 1 - n) : 2;  // tiles issued after tile n
+        const int allow = (int)younger * pw;
+        if (allow >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (allow >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (allow >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile n has landed for everyone; everyone is done with tile n - 1
+        if (n + 3 < n_tiles) tile_dma(t0 + (n + 3) * tstride, slot_of(n + 3));
+        if (act) {
+          const float* zimg = slot_of(n);
+          const float* aimg = zimg + kOp;
+          // the whole 32-point tile in ONE v_mfma_f32_16x16x32_bf16 per (m, n2): a lane's eight k-slots are the points
+          // 4 g + j and 16 + 4 g + j (the two transposed reads of operand16), the same assignment for both operands
+          bf16x4 am[2][4], bn[2][4];
+          f32x4 none = zero4;
+          int iv = i, gv = g;
+          asm volatile("" : "+v"(iv), "+v"(gv));
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            operand16(zimg, true, rg, iv, gv, t2, am[t2], cg == 0, dbacc);
+            operand16(aimg, true, cg, iv, gv, t2, bn[t2], false, none);
+          }
+          bf16x8w a8[4], b8[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            a8[m] = __builtin_shufflevector(am[0][m], am[1][m], 0, 1, 2, 3, 4, 5, 6, 7);
+            b8[m] = __builtin_shufflevector(bn[0][m], bn[1][m], 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2)
+              acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[m], b8[n2], acc[m][n2], 0, 0, 0);
+        }
+      }
+      t0 = t1;  // (the loop below has nothing left)
+    }
+  }
   int cur = 1;
   for (long t = t0; t < t1; t += tstep) {
     cur ^= 1;
@@ -242,6 +293,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
           // points 16 t2 + 4 g + j, j < 4: chunk c of row r lives at chunk position c ^ (r & 15)
+          // (two 16-point v_mfma_f32_16x16x16_bf16 steps here: the 32-point form of the four-slot loop above costs this
+          // mixed-format path 7 spilled registers inside the tile loop, 2.04 -> 2.30 ms on the config-3 decoder launch)
           bf16x4 am[4], bn[4];
           f32x4 none = zero4;
           // (the fragment addresses are recomputed per tile from an opaque copy of the lane ids: hoisted out of the
