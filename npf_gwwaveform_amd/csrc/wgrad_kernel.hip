@@ -34,6 +34,7 @@ struct WgradJobs {
 };
 
 __device__ __forceinline__ void wg_dma16(const float* src, float* lds_dst_wave_uniform) {
+  // (aux = 2, nt, for these read-once tiles was measured: config 3 12.85 -> 12.95 ms; default policy kept)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
 }
