@@ -108,6 +108,30 @@ def test_bf16_mode_matches_the_bf16_oracle(name):
     print(f"{name}: loc rel L2 {l2_16:.1e} (fp32 oracle: {l2_32:.1e}); worst gradient rel L2 {worst:.1e} (fp32 oracle: {worst32:.1e})")
 
 
+@pytest.mark.parametrize("name", ["g3_attncnp_c2", "g4_attnlnp_c2", "g1_cnp_c1"])
+def test_fused_layer_stores_change_nothing(name, monkeypatch):
+    """NPF_F_STORE_IN / NPF_F_STORE_BITS (a STORE_PT in front of a bf16 LINEAR and a STORE_MASK behind a ReLU layer ride
+    inside the layer) move stores, not arithmetic: outputs, loss and every gradient are BIT-identical to the
+    same step with the stores as separate ops (the NPF_NO_FUSED_STORE debug switch)."""
+    from npf_gwwaveform_amd import chain as CH
+
+    case = specs.CASES[name] if name in specs.CASES else CASES[name]
+    params = specs.make_params(case, seed=11)
+    inp = specs.make_inputs(case, seed=4321)
+    runs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(CH, "FUSE_STORES", fuse)
+        model, out, loss = _hip_bf16(case, inp, params)
+        runs.append((out[0].base_dist.loc.detach().clone(), out[0].base_dist.scale.detach().clone(), loss.detach().clone(),
+                     {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}))
+    (loc_a, sc_a, loss_a, g_a), (loc_b, sc_b, loss_b, g_b) = runs
+    assert torch.equal(loc_a, loc_b) and torch.equal(sc_a, sc_b) and torch.equal(loss_a, loss_b)
+    for k in g_a:
+        assert (g_a[k] is None) == (g_b[k] is None), k
+        if g_a[k] is not None:
+            assert torch.equal(g_a[k], g_b[k]), k
+
+
 def test_full_size_config3_properties():
     """BASELINE config 3 at full size (bf16 mode, 1024 tasks x 1024 targets): the size-independent properties
     of test_hip_models.py::test_full_size_config2_properties, in the bf16 compute mode.  Task and target
