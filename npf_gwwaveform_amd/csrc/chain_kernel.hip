@@ -967,6 +967,8 @@ __global__ __launch_bounds__(64 * WAVES, (MAXB <= 16 && WAVES == 4) ? 2 : 1) voi
     const unsigned wave_slot = __builtin_amdgcn_s_getreg(6148);  // HW_REG_HW_ID[3:0] = WAVE_ID
     if (wave_slot & 1) __builtin_amdgcn_s_sleep(40);  // (bf16 instance: 0 / 10 / 20 / 40 / 80 measured, within 1 % of each other)
   }
+  // (Staggering the first round of workgroups by XCD -- block b runs on XCD b % 8 -- so that the 256 CUs do not reach the
+  // stores between two layers together was measured: config 2 10.05 -> 10.17 ms, config 3 12.88 -> 12.93: not kept.)
 
   f32x4 cur[kMaxB16], out[kMaxB16];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
