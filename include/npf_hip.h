@@ -272,7 +272,9 @@ int npf_cast_bf16_weights(const float *src, int32_t n_rows, int32_t n_cols, int3
 
 /* Batched weight preparation: up to NPF_MAX_WPREP_JOBS of the two functions above in ONE launch (a chain's
  * dgrad needs W^T -- or, in the bf16 mode, an image -- of every layer; one 5 us launch per layer otherwise).
- * kind: 0 = fp32 transpose (as npf_transpose, src row stride ld), 1 = bf16 image, 2 = bf16 image of src^T. */
+ * kind: 0 = fp32 transpose (as npf_transpose, src row stride ld), 1 = bf16 image, 2 = bf16 image of src^T;
+ * 5 / 6 = kinds 1 / 2 with every image row zero-padded to 256 inputs (a layer with <= 32 real inputs whose remaining
+ * input registers are known to be zero then runs as a 256-input layer on the pipelined path). */
 typedef struct npf_wprep_job {
   const float *src; /* row-major [n_rows][n_cols], row stride ld floats */
   void *dst;        /* kind 0: float [n_cols][n_rows]; kind 1 / 2: bf16 image, 16-byte aligned */

@@ -31,6 +31,10 @@ DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microben
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
 PT16_INTERNAL = os.environ.get("NPF_NO_PT16", "0") != "1"  # bf16 mode: backward-only tensors as bf16 tiles (debug switch)
 MASK_BITS = os.environ.get("NPF_NO_MASK_BITS", "0") != "1"  # bf16 mode: ReLU masks of the backward pass as bits (debug switch)
+# bf16 mode: a layer with <= 32 inputs and 256 outputs right behind LOAD_ROWS (x-encoder first layers, the dgrad of a narrow
+# output layer) costs twice a 256 -> 256 layer on the generic slab loop (one DMA round trip per slab); with its image
+# rows zero-padded to 256 inputs -- the other input registers ARE zero behind LOAD_ROWS -- it is a pipelined layer
+PAD_SMALL_K = os.environ.get("NPF_NO_PAD_SMALL_K", "0") != "1"
 DUMP_PROGRAMS = os.environ.get("NPF_DUMP_PROGRAMS", "0") == "1"
 FUSE_STORES = os.environ.get("NPF_NO_FUSED_STORE", "0") != "1"  # bf16 mode: STORE_PT + LINEAR -> LINEAR | F_STORE_IN (debug switch)
 
@@ -137,6 +141,7 @@ class Program:
         self.ops: List[L.NpfOp] = []
         self.keep: list = []  # tensors referenced by raw pointer must outlive the launch call
         self.bf16 = False     # every LINEAR takes a bf16 weight image (linear_bf16)
+        self._pad_k = 0       # sum over zero-padded layers (PAD_SMALL_K) of (padded K - K) * N: not algorithmic work
 
     def _op(self, **kw) -> None:
         if len(self.ops) >= L.NPF_MAX_OPS:
@@ -259,7 +264,7 @@ class Program:
                  p1=self._p(bias), p2=self._p(addend), s0=w_task_stride, s1=b_task_stride)
 
     def linear_bf16(self, W_img, K, N, bias=None, relu=False, addend=None, addend_modulus=0, b_task_stride=0,
-                    per_task=False):
+                    per_task=False, true_K=None):
         """LINEAR in the bf16 compute mode: ``W_img`` = ``cast_bf16_weights`` image [N, pad32(K)] (bf16), or with
         ``per_task`` a ``store_wb`` / ``store_trb`` image [n_tasks, rows >= N, pad32(K)] of activations."""
         if self.ops and not self.bf16 and any(o.op == L.OP_LINEAR for o in self.ops):
@@ -270,6 +275,8 @@ class Program:
         if not ok:
             raise ValueError(f"bad bf16 weight image {tuple(W_img.shape)} {W_img.dtype} for a {K}->{N} layer")
         self.bf16 = True
+        if true_K is not None:  # (image rows zero-padded from true_K to K inputs)
+            self._pad_k += (K - true_K) * N
         p_add, fl_add = self._pt(addend) if addend is not None else (None, 0)  # (fp32 PT32 or PT16)
         flags = (L.F_RELU if relu else 0) | ((L.F_ADD_PT | fl_add) if addend is not None else 0)
         # a store of the layer's input right in front of it rides inside the layer (NPF_F_STORE_IN): the pipelined
@@ -299,7 +306,7 @@ class Program:
 
     def flops(self) -> int:
         """Algorithmic GEMM FLOPs of one launch: 2*K*N per LINEAR per valid point."""
-        return sum(2 * o.i0 * o.i1 for o in self.ops if o.op == L.OP_LINEAR) * self.n_tasks * self.pts
+        return (sum(2 * o.i0 * o.i1 for o in self.ops if o.op == L.OP_LINEAR) - 2 * self._pad_k) * self.n_tasks * self.pts
 
     def hbm_bytes(self) -> int:
         """Algorithmic HBM bytes of one launch: every per-point tensor the program loads or stores
@@ -331,7 +338,7 @@ class Program:
                     per_pt += (2 if o.flags & L.F_STORE_P16 else 4) * pad32(o.i0)
                 per_task = o.i2 != L.W_ROWMAJOR or o.s0 != 0
                 fixed += 4 * o.i0 * o.i1 * (self.n_tasks if per_task else 1)
-        return per_pt * pts + fixed
+        return per_pt * pts + fixed - 4 * self._pad_k
 
     def launch(self) -> None:
         if not self.ops:
@@ -344,6 +351,10 @@ class Program:
             PROFILE.append(("chain_kernel", self.flops(), ev0, ev1, self.hbm_bytes()))
         else:
             self._launch()
+
+    def only_rows_loaded(self) -> bool:
+        """cur = a LOAD_ROWS result (<= 32 features, every other register zero), stored at most since."""
+        return bool(self.ops) and self.ops[0].op == L.OP_LOAD_ROWS and all(o.op == L.OP_STORE_PT for o in self.ops[1:])
 
     def describe(self) -> str:
         """One line per op (debugging aid: NPF_DUMP_PROGRAMS=1 prints it at every launch)."""
@@ -461,10 +472,13 @@ def cast_bf16_weights(W: torch.Tensor, transposed: bool = False) -> torch.Tensor
 
 def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]]) -> List[torch.Tensor]:
     """``npf_prepare_weights``: for every (W [N, K] row-major with unit column stride, kind) one output, all in one
-    launch per 32 matrices -- kind 0: W^T (fp32 [K, N]); 1: the bf16 image of W; 2: the bf16 image of W^T."""
+    launch per 32 matrices -- kind 0: W^T (fp32 [K, N]); 1: the bf16 image of W; 2: the bf16 image of W^T; 5 / 6: images 1 / 2
+    with their rows zero-padded to 256 inputs (PAD_SMALL_K)."""
     outs: List[torch.Tensor] = []
     lib = L.load()
     if os.environ.get("NPF_NO_BATCH_PREP") == "1":  # debug switch: one launch per matrix
+        if any(kind & 4 for _, kind in specs):
+            raise RuntimeError("NPF_NO_BATCH_PREP needs NPF_NO_PAD_SMALL_K=1 as well")
         return [transpose(W.contiguous()) if kind == 0 else cast_bf16_weights(W, transposed=kind == 2) for W, kind in specs]
     for i0 in range(0, len(specs), L.NPF_MAX_WPREP_JOBS):
         chunk = specs[i0:i0 + L.NPF_MAX_WPREP_JOBS]
@@ -476,8 +490,8 @@ def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]]) -> List[torch.Ten
             if kind == 0:
                 out = torch.empty((K, N), dtype=torch.float32, device=W.device)
             else:
-                rows, cols = (K, N) if kind == 2 else (N, K)
-                out = torch.empty((rows, pad32(cols)), dtype=torch.bfloat16, device=W.device)
+                rows, cols = (K, N) if kind & 3 == 2 else (N, K)
+                out = torch.empty((rows, 256 if kind & 4 else pad32(cols)), dtype=torch.bfloat16, device=W.device)
             arr[j].src, arr[j].dst = L.ptr(W, strided=True), out.data_ptr()
             arr[j].n_rows, arr[j].n_cols, arr[j].ld, arr[j].kind = N, K, W.stride(0), kind
             outs.append(out)
@@ -718,9 +732,14 @@ class _ChainFn(torch.autograd.Function):
                 saved[(i, "out")] = ensure_saved(F, internal=True)
 
         images = {}  # bf16 mode: the weight images of all LINEAR steps, one launch
+        pad_k = set()  # steps run as zero-padded 256-input layers (PAD_SMALL_K)
         if bf16:
-            lin = [st.t["W"] for st in chain.steps if st.kind == "linear"]
-            images = dict(zip(lin, prepare_weights([(T[w], 1) for w in lin])))
+            for i, st in enumerate(chain.steps):
+                if (PAD_SMALL_K and st.kind == "linear" and i > 0 and chain.steps[i - 1].kind == "input_rows" and st.a["K"] <= 32
+                        and st.a["N"] == 256 and st.t["add"] < 0 and not st.a.get("add_rm")):
+                    pad_k.add(i)
+            lin = [(i, st.t["W"]) for i, st in enumerate(chain.steps) if st.kind == "linear"]
+            images = dict(zip(lin, prepare_weights([(T[w], 5 if i in pad_k else 1) for i, w in lin])))
         for i, st in enumerate(chain.steps):
             upstream_before.append(upstream)
             k, a = st.kind, st.a
@@ -746,9 +765,12 @@ class _ChainFn(torch.autograd.Function):
                 if a.get("add_rm") and train and (upstream or needs_grad[W] or needs_grad[add]):
                     raise NotImplementedError("row-major addends carry no gradient (inference path)")
                 if bf16:
-                    prog.linear_bf16(images[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
-                                     addend=T[add] if add >= 0 else None, addend_modulus=a["mod"],
-                                     b_task_stride=(T[b].stride(0) if a["bpt"] else 0))
+                    padded = i in pad_k and prog.only_rows_loaded()
+                    if i in pad_k and not padded:
+                        raise AssertionError("zero-padded layer not behind LOAD_ROWS")
+                    prog.linear_bf16(images[(i, W)], 256 if padded else a["K"], a["N"], bias=T[b] if b >= 0 else None,
+                                     relu=a["relu"], addend=T[add] if add >= 0 else None, addend_modulus=a["mod"],
+                                     b_task_stride=(T[b].stride(0) if a["bpt"] else 0), true_K=a["K"] if padded else None)
                 else:
                     prog.linear(T[W], a["K"], a["N"], bias=T[b] if b >= 0 else None, relu=a["relu"],
                                 addend=T[add] if add >= 0 else None, addend_modulus=a["mod"], ldw=T[W].stride(0),
@@ -875,8 +897,17 @@ class _ChainFn(torch.autograd.Function):
         n_out = sum(1 for s in chain.steps if s.kind in ("tap", "output_pt", "output_rows", "store_tr", "store_wb", "store_trb"))
         assert len(gouts) == n_out
         # W^T (bf16 mode: the transposed image) of every layer the dgrad passes through, one launch
-        lin = [st.t["W"] for i, st in enumerate(chain.steps) if st.kind == "linear" and upstream_before[i]]
-        w_t = dict(zip(lin, prepare_weights([(T[w], 2 if ctx.bf16 else 0) for w in lin]))) if lin else {}
+        lin = [(i, st.t["W"]) for i, st in enumerate(chain.steps) if st.kind == "linear" and upstream_before[i]]
+        # (PAD_SMALL_K: the dgrad of a narrow last layer -- dOut rows behind LOAD_ROWS, <= 32 of them, 256 outputs -- as a
+        # zero-padded 256-input layer)
+        pad_t = set()
+        if ctx.bf16 and PAD_SMALL_K and lin:
+            i_last = max(i for i, _ in lin)
+            st_l = chain.steps[i_last]
+            tail = [s.kind for s in chain.steps[i_last + 1:]]
+            if st_l.a["N"] <= 32 and st_l.a["K"] == 256 and tail == ["output_rows"] and not st_l.a["relu"]:
+                pad_t.add(i_last)
+        w_t = dict(zip(lin, prepare_weights([(T[w], (6 if i in pad_t else 2) if ctx.bf16 else 0) for i, w in lin]))) if lin else {}
         for i in range(len(chain.steps) - 1, -1, -1):
             st = chain.steps[i]
             k, a = st.kind, st.a
@@ -920,9 +951,12 @@ class _ChainFn(torch.autograd.Function):
                         grads[add] = (dz, a["mod"])  # resolved after the launch
                 if upstream_before[i]:
                     if ctx.bf16:
-                        prog.linear_bf16(w_t[W], a["N"], a["K"])
+                        padded = i in pad_t and prog.only_rows_loaded()
+                        if i in pad_t and not padded:
+                            raise AssertionError("zero-padded dgrad layer not behind LOAD_ROWS")
+                        prog.linear_bf16(w_t[(i, W)], 256 if padded else a["N"], a["K"], true_K=a["N"] if padded else None)
                     else:
-                        prog.linear(w_t[W], a["N"], a["K"])  # W^T [K, N]
+                        prog.linear(w_t[(i, W)], a["N"], a["K"])  # W^T [K, N]
                 else:
                     started = False  # nothing upstream needs this gradient
                     break

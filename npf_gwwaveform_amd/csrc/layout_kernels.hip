@@ -164,9 +164,9 @@ __global__ void prepare_weights_kernel(const WprepJobs J) {
     }
   } else {
     unsigned short* __restrict__ dst = (unsigned short*)jb.dst;
-    const bool transposed = jb.kind == 2;
+    const bool transposed = (jb.kind & 3) == 2;
     const int rows = transposed ? jb.n_cols : jb.n_rows, cols = transposed ? jb.n_rows : jb.n_cols, ld = jb.ld;
-    const int Kp = ((cols + 31) >> 5) * 32;
+    const int Kp = (jb.kind & 4) ? 256 : ((cols + 31) >> 5) * 32;  // kinds 5, 6: rows zero-padded to 256 inputs
     const size_t total = (size_t)rows * Kp;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
       const int r = idx / Kp, q = idx - (size_t)r * Kp;
@@ -302,11 +302,15 @@ extern "C" int npf_prepare_weights(const npf_wprep_job_t* jobs, int32_t n_jobs, 
   size_t most = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const npf_wprep_job_t& b = jobs[j];
-    if (!b.src || !b.dst || b.n_rows <= 0 || b.n_cols <= 0 || b.ld < b.n_cols || b.kind < 0 || b.kind > 2) return NPF_EINVAL;
+    const bool kind_ok = (b.kind >= 0 && b.kind <= 2) || b.kind == 5 || b.kind == 6;
+    if (!b.src || !b.dst || b.n_rows <= 0 || b.n_cols <= 0 || b.ld < b.n_cols || !kind_ok) return NPF_EINVAL;
     if (b.kind != 0 && (((uintptr_t)b.dst) & 15)) return NPF_EINVAL;
+    if ((b.kind == 5 && b.n_cols > 256) || (b.kind == 6 && b.n_rows > 256)) return NPF_EINVAL;  // (the image's inputs)
     J.job[j] = b;
-    const size_t blocks = b.kind == 0 ? (size_t)((b.n_rows + 31) / 32) * ((b.n_cols + 31) / 32)
-                                      : ((size_t)b.n_rows * b.n_cols + 255) / 256;
+    const size_t img_rows = (b.kind & 3) == 2 ? b.n_cols : b.n_rows;
+    const size_t blocks = b.kind == 0   ? (size_t)((b.n_rows + 31) / 32) * ((b.n_cols + 31) / 32)
+                          : (b.kind & 4) ? (img_rows * 256 + 255) / 256
+                                         : ((size_t)b.n_rows * b.n_cols + 255) / 256;
     most = blocks > most ? blocks : most;
   }
   for (int j = n_jobs; j < NPF_MAX_WPREP_JOBS; ++j) J.job[j] = jobs[0];

@@ -111,8 +111,9 @@ def test_bf16_mode_matches_the_bf16_oracle(name):
 @pytest.mark.parametrize("name", ["g3_attncnp_c2", "g4_attnlnp_c2", "g1_cnp_c1"])
 def test_fused_layer_stores_change_nothing(name, monkeypatch):
     """NPF_F_STORE_IN / NPF_F_STORE_BITS (a STORE_PT in front of a bf16 LINEAR and a STORE_MASK behind a ReLU layer ride
-    inside the layer) move stores, not arithmetic: outputs, loss and every gradient are BIT-identical to the
-    same step with the stores as separate ops (the NPF_NO_FUSED_STORE debug switch)."""
+    inside the layer) move stores, not arithmetic, and PAD_SMALL_K (a <= 32-input layer behind LOAD_ROWS run
+    as a zero-padded 256-input pipelined layer) only adds exact zeros: outputs, loss and every gradient are BIT-identical
+    to the same step with both switched off (NPF_NO_FUSED_STORE, NPF_NO_PAD_SMALL_K)."""
     from npf_gwwaveform_amd import chain as CH
 
     case = specs.CASES[name] if name in specs.CASES else CASES[name]
@@ -121,6 +122,7 @@ def test_fused_layer_stores_change_nothing(name, monkeypatch):
     runs = []
     for fuse in (True, False):
         monkeypatch.setattr(CH, "FUSE_STORES", fuse)
+        monkeypatch.setattr(CH, "PAD_SMALL_K", fuse)
         model, out, loss = _hip_bf16(case, inp, params)
         runs.append((out[0].base_dist.loc.detach().clone(), out[0].base_dist.scale.detach().clone(), loss.detach().clone(),
                      {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}))

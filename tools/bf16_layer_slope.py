@@ -72,6 +72,14 @@ def _time(name, CH, torch, L):
     prog = CH.Program(n_tasks, pts, False)
     prog.load_pt(x, 256)
     keep = []
+    if SHAPE == "small_k":  # pairs of a 256->4 and a 4->256 layer (the generic slab loop: x-encoder / output-layer shapes)
+        down = CH.cast_bf16_weights(torch.randn(4, 256, device=dev) / 16)
+        up = CH.cast_bf16_weights(torch.randn(256, 4, device=dev) / 2)
+        for b in bs:
+            prog.linear_bf16(down, 256, 4, bias=None, relu=False)
+            prog.linear_bf16(up, 4, 256, bias=b, relu=True)
+        imgs, bs = [], []
+        keep += [down, up]
     for img, b in zip(imgs, bs):
         if SHAPE == "bwd_train":  # dgrad layer: mask bits in the epilogue, dZ stored for the wgrad launch
             prog.linear_bf16(img, 256, 256, bias=None, relu=False)
