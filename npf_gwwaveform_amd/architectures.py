@@ -7,9 +7,9 @@ Mirrors, for the hot path only:
                                 npf/architectures/encoders.py:130-213
   * ``get_attender("scaledot")`` / ``DotAttender``
                                 npf/architectures/attention.py:16-86,89-220
-Everything else the reference offers in those files (other activations, dropout,
-residual MLPs, concatenating merge, the other attention flavours) raises
-``NotImplementedError`` here instead of silently running somewhere else.
+``MLP(is_res=True)`` and the concatenating merge are covered too; what else the reference offers in
+those files (other activations, dropout, the other attention flavours) raises ``NotImplementedError``
+here instead of silently running somewhere else.
 
 ``forward`` takes row-major device tensors like the reference; internally every module can
 also append itself to a :class:`~npf_gwwaveform_amd.chain.Chain` (``append_to``), which is how
@@ -51,8 +51,6 @@ class MLP(nn.Module):
         _check_relu(activation)
         if dropout != 0:
             raise NotImplementedError("dropout is not on the hot path (the reference's 1-D models use dropout=0)")
-        if is_res:
-            raise NotImplementedError("residual MLPs are not on the hot path")
         self.input_size, self.output_size, self.n_hidden_layers, self.is_res = input_size, output_size, n_hidden_layers, is_res
         self.hidden_size = hidden_size
         if is_force_hid_smaller and self.hidden_size > max(output_size, input_size):
@@ -85,9 +83,15 @@ class MLP(nn.Module):
     def layers(self):
         return [self.to_hidden, *self.linears, self.out]
 
-    def append_to(self, ch: Chain, first_addend=None, first_addend_modulus=0) -> Chain:
+    def append_to(self, ch: Chain, skip_first: bool = False, skip_last: bool = False) -> Chain:
+        """cur <- MLP(cur).  ``skip_first``: cur already holds the activated output of ``to_hidden`` (a
+        concatenating merge computes that layer as two accumulating halves); ``skip_last``: stop in front of
+        ``out``.  With ``is_res`` every hidden-to-hidden layer adds its input back after the activation
+        (mlp.py:100-104)."""
         ls = self.layers()
         for j, lin in enumerate(ls):
+            if (j == 0 and skip_first) or (j == len(ls) - 1 and skip_last):
+                continue
             W = lin.weight
             if j == 0 and W.shape[1] % 4 != 0 and W.shape[1] == ch.F:
                 # skinny first layers (x: 1-2 features, y: 2): zero-pad the fan-in to a multiple of 4
@@ -96,7 +100,7 @@ class MLP(nn.Module):
                 pad = -W.shape[1] % 4
                 W = torch.nn.functional.pad(W, (0, pad))
                 ch.F = W.shape[1]
-            ch.linear(W, lin.bias, relu=(j < len(ls) - 1))
+            ch.linear(W, lin.bias, relu=(j < len(ls) - 1), residual=(self.is_res and 0 < j < len(ls) - 1))
         return ch
 
     def forward(self, x):
@@ -112,9 +116,7 @@ class MLP(nn.Module):
             return FN.unpack_pt(y, rows, self.output_size).reshape(*lead, self.output_size)
         # wide output layer (e.g. the latent encoder's r -> 2 z): run the trunk once, then the
         # output layer in row blocks of <= 256 outputs
-        for lin in self.layers()[:-1]:
-            ch.linear(lin.weight, lin.bias, relu=True)
-        (h,) = ch.output_pt().run()
+        (h,) = self.append_to(ch, skip_last=True).output_pt().run()
         outs = []
         for lo in range(0, self.output_size, NPF_MAX_FUSED_ROW):
             hi = min(lo + NPF_MAX_FUSED_ROW, self.output_size)
@@ -126,33 +128,74 @@ class MLP(nn.Module):
 
 
 class MergeFlatInputs(nn.Module):
-    """Two-input wrapper, sum-merge flavour: ``flat_module(relu(x1 + resizer(x2)))``
-    (npf/architectures/encoders.py:130-183)."""
+    """Two-input wrapper (npf/architectures/encoders.py:130-183).  Sum merge (``is_sum_merge=True``, what
+    the reference's encoders / decoders use): ``flat_module(relu(x1 + resizer(x2)))``.  Concatenating merge
+    (the constructor default): ``flat_module(cat(x1, x2))`` -- the concatenation is never materialised: the
+    first layer of the flat module runs as two accumulating halves, ``W[:, :x1_dim] x1 + W[:, x1_dim:] x2 + b``."""
 
     def __init__(self, FlatModule, x1_dim, x2_dim, n_out, is_sum_merge=False, **kwargs):
         super().__init__()
-        if not is_sum_merge:
-            raise NotImplementedError("only is_sum_merge=True (the reference's default encoders/decoders) is on the hot path")
-        self.is_sum_merge = True
-        self.resizer = MLP(x2_dim, x1_dim)
-        self.flat_module = FlatModule(x1_dim, n_out, **kwargs)
+        self.is_sum_merge = bool(is_sum_merge)
+        self.x1_dim, self.x2_dim = x1_dim, x2_dim
+        if self.is_sum_merge:
+            self.resizer = MLP(x2_dim, x1_dim)
+            self.flat_module = FlatModule(x1_dim, n_out, **kwargs)
+        else:
+            self.flat_module = FlatModule(x1_dim + x2_dim, n_out, **kwargs)
         if not isinstance(self.flat_module, (MLP, SelfAttention)):
             raise NotImplementedError("the HIP path needs an MLP or a SelfAttention as the flat module")
+        if not self.is_sum_merge and not isinstance(self.flat_module, MLP):
+            raise NotImplementedError("a concatenating merge needs an MLP flat module on the HIP path")
 
     def reset_parameters(self):  # the reference's weights_init is a no-op here (SURVEY.md 8a row 12)
         pass
+
+    def _halves(self):
+        """(W1, W2, b) of the concatenating merge's first layer: column slices of ``to_hidden.weight``."""
+        lin = self.flat_module.to_hidden
+        return lin.weight[:, : self.x1_dim], lin.weight[:, self.x1_dim:], lin.bias
+
+    def _x1_half(self, x1_pt: torch.Tensor, pts: int) -> torch.Tensor:
+        """W1 x1 of a concatenating merge as a PT32 tensor (its own launch: x1 is not the chain's cur)."""
+        ch = Chain(x1_pt.shape[0], pts, x1_pt.device)
+        ch.input_pt(x1_pt, self.x1_dim).linear(self._halves()[0], None).output_pt()
+        return ch.run()[0]
 
     def append_to(self, ch: Chain, x1_pt: Optional[torch.Tensor] = None, x1_modulus: int = 0,
                   x1_taskvec: bool = False, x1_rm: bool = False) -> Chain:
         """cur = x2 on entry.  ``x1_pt``: PT32 tensor added before the ReLU (``x1_rm``: it is a
         row-major [tasks, pts, x1_dim] tensor instead)."""
+        if isinstance(self.flat_module, SelfAttention):
+            raise NotImplementedError("a SelfAttention flat module is not one chain: use run_pt")
+        if not self.is_sum_merge:
+            if x1_rm:
+                raise NotImplementedError("row-major x1 with a concatenating merge")
+            _, W2, b = self._halves()
+            ch.linear(W2, b, relu=True, addend=self._x1_half(x1_pt, ch.pts), addend_modulus=x1_modulus)
+            return self.flat_module.append_to(ch, skip_first=True)
         rl = self.resizer.layers()
         for j, lin in enumerate(rl[:-1]):
             ch.linear(lin.weight, lin.bias, relu=True)
         ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=x1_modulus, addend_rm=x1_rm)
-        if isinstance(self.flat_module, SelfAttention):
-            raise NotImplementedError("a SelfAttention flat module is not one chain: use run_pt")
         return self.flat_module.append_to(ch)
+
+    def append_taskvec_to(self, ch: Chain, vec_rows: torch.Tensor, modulus: int = 0) -> Chain:
+        """cur = x1 on entry; x2 is one row-major vector per task, ``vec_rows`` [n_tasks, x2_dim] (np.py:107-110,161:
+        the reference expands it over the targets and recomputes its half per target; here that half runs
+        once per task and enters as a per-task vector)."""
+        if not isinstance(self.flat_module, MLP):
+            raise NotImplementedError("a per-task x2 needs an MLP flat module")
+        if self.is_sum_merge:
+            tv = self.resizer(vec_rows)
+        else:
+            W1, W2, b = self._halves()
+            tv = _rows_linear(W2, b, vec_rows)
+            ch.linear(W1, None)
+        Fp = -(-tv.shape[1] // 32) * 32
+        if tv.shape[1] != Fp:
+            tv = torch.nn.functional.pad(tv, (0, Fp - tv.shape[1]))
+        ch.add_taskvec(tv.contiguous(), relu=True, modulus=modulus)
+        return self.flat_module.append_to(ch, skip_first=not self.is_sum_merge)
 
     def run_pt(self, ch: Chain, x1_pt, n_tasks: int, pts: int, with_tr: bool = False, **kw) -> PTensor:
         """Finish ``ch`` (cur = x2) with this module and run it: a :class:`PTensor` [n_tasks, pts, n_out]
@@ -177,7 +220,7 @@ class MergeFlatInputs(nn.Module):
         if n2 % max(n1, 1) != 0:
             raise NotImplementedError("unsupported broadcast between x1 and x2")
         x2 = x2.expand(*lead2, T, x2.shape[-1]) if x2.shape[-2] != T else x2
-        n_out = self.flat_module.output_size
+        n_out = self.flat_module.out_dim if isinstance(self.flat_module, SelfAttention) else self.flat_module.output_size
         if T == 0 or n2 == 0:
             return x1.new_zeros(*lead2, T, n_out)
         if isinstance(self.flat_module, SelfAttention):
@@ -189,7 +232,7 @@ class MergeFlatInputs(nn.Module):
         d2 = x2.shape[-1]
         no_grad = not torch.is_grad_enabled() or not (x1.requires_grad or x2.requires_grad or
                                                       any(p.requires_grad for p in self.parameters()))
-        if no_grad and d1 % 32 == 0 and d2 % 32 == 0:
+        if self.is_sum_merge and no_grad and d1 % 32 == 0 and d2 % 32 == 0:
             # inference: the row-major module-boundary tensors go straight into the chain (no PT32
             # packing pass over x1 and x2)
             ch.input_rm(x2.reshape(n2, T, d2).contiguous(), d2)
@@ -202,6 +245,14 @@ class MergeFlatInputs(nn.Module):
             return y[..., :n_out].reshape(*lead2, T, n_out)
         (y,) = ch.output_pt().run()
         return FN.unpack_pt(y, T, n_out).reshape(*lead2, T, n_out)
+
+
+def _rows_linear(W: torch.Tensor, b: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """x [rows, K] -> x W^T + b [rows, N] as one chain launch over the rows."""
+    rows, K = x.shape
+    ch = Chain(1, rows, x.device)
+    ch.input_pt(FN.pack_pt(x.reshape(1, rows, K)), K).linear(W, b).output_pt()
+    return FN.unpack_pt(ch.run()[0], rows, W.shape[0]).reshape(rows, W.shape[0])
 
 
 def merge_flat_input(module, is_sum_merge=False, **kwargs):
@@ -255,7 +306,7 @@ class DotAttender(nn.Module):
 
         scale = 1.0 / math.sqrt(self.kq_size) if self.is_scale else 1.0
         return long_scaledot_attention(queries_pt, keys_pt, values_pt, n_keys, n_queries, self.value_size, scale,
-                                       k_tr=keys_tr, v_tr=values_tr)
+                                       k_tr=keys_tr, v_tr=values_tr, d=self.kq_size)
 
     def forward(self, keys, queries, values):
         B, C, d = keys.shape

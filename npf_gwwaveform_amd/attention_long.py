@@ -68,7 +68,7 @@ def _contract_keys_op(prog: Program, x_pt: torch.Tensor, x_tr: Optional[torch.Te
 
 class _LongScaledDot(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q_pt, k_pt, v_pt, n_keys, n_queries, r, scale, k_tr, v_tr):
+    def forward(ctx, q_pt, k_pt, v_pt, n_keys, n_queries, r, scale, k_tr, v_tr, d):
         B, dev = q_pt.shape[0], q_pt.device
         T = n_queries
         blocks = _blocks(n_keys)
@@ -79,8 +79,8 @@ class _LongScaledDot(torch.autograd.Function):
         run = _Launcher(B, T)
         for j, (c0, cj) in enumerate(blocks):
             prog = run.room(3)
-            prog.load_pt(q_pt, r)
-            _score_op(prog, k_pt, c0, cj, r)
+            prog.load_pt(q_pt, d)
+            _score_op(prog, k_pt, c0, cj, d)
             prog.softmax(cj, scale, mode=1, stats=stats[j])
         run.flush()
         m = stats[..., 0].amax(dim=0)                                            # [B, T]
@@ -91,8 +91,8 @@ class _LongScaledDot(torch.autograd.Function):
         probs = []
         for j, (c0, cj) in enumerate(blocks):
             prog = run.room(7)
-            prog.load_pt(q_pt, r)
-            _score_op(prog, k_pt, c0, cj, r)
+            prog.load_pt(q_pt, d)
+            _score_op(prog, k_pt, c0, cj, d)
             prog.softmax(cj, scale, mode=2, stats=row)
             if train:
                 p_j = pt_empty(B, T, cj, dev)
@@ -103,7 +103,7 @@ class _LongScaledDot(torch.autograd.Function):
                 prog.add_pt(out, r)
             prog.store_pt(out, r)
             run.flush()  # one launch per block: the running sum is re-read by the next block
-        ctx.geom = (B, T, n_keys, r, scale)
+        ctx.geom = (B, T, n_keys, r, scale, d)
         ctx.tr = (k_tr, v_tr)
         ctx.save_for_backward(q_pt, k_pt, v_pt, out, *probs)
         ctx.set_materialize_grads(False)
@@ -112,15 +112,15 @@ class _LongScaledDot(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         if d_out is None:
-            return (None,) * 9
-        B, T, n_keys, r, scale = ctx.geom
+            return (None,) * 10
+        B, T, n_keys, r, scale, d = ctx.geom
         k_tr, v_tr = ctx.tr
         q_pt, k_pt, v_pt, out, *probs = ctx.saved_tensors
         dev = q_pt.device
         d_out = d_out.contiguous()
         need_q, need_k, need_v = ctx.needs_input_grad[:3]
         blocks = _blocks(n_keys)
-        dq = pt_empty(B, T, r, dev) if need_q else None
+        dq = pt_empty(B, T, d, dev) if need_q else None
         run = _Launcher(B, T)
         jobs, dk_parts, dv_parts = [], [], []
         for j, (c0, cj) in enumerate(blocks):
@@ -132,14 +132,14 @@ class _LongScaledDot(torch.autograd.Function):
             ds_j = pt_empty(B, T, cj, dev)
             prog.store_pt(ds_j, cj)
             if need_q:
-                _contract_keys_op(prog, k_pt, k_tr, c0, cj, r)                   # dQ_j = dS_j K_j
+                _contract_keys_op(prog, k_pt, k_tr, c0, cj, d)                   # dQ_j = dS_j K_j
                 if j > 0:
-                    prog.add_pt(dq, r)
-                prog.store_pt(dq, r)
+                    prog.add_pt(dq, d)
+                prog.store_pt(dq, d)
             run.flush()  # (as in the forward pass: dq is re-read by the next block's launch)
             if need_k:
-                dk_j = pt_empty(B, cj, r, dev)
-                jobs.append(dict(dZ=ds_j, A=q_pt, N=cj, K=r, dW=dk_j, per_task=True))
+                dk_j = pt_empty(B, cj, d, dev)
+                jobs.append(dict(dZ=ds_j, A=q_pt, N=cj, K=d, dW=dk_j, per_task=True))
                 dk_parts.append(dk_j)
             if need_v:
                 dv_j = pt_empty(B, cj, r, dev)
@@ -154,18 +154,21 @@ class _LongScaledDot(torch.autograd.Function):
             assert g.shape == like.shape, (g.shape, like.shape)
             return g
 
-        return dq, assemble(dk_parts, k_pt), assemble(dv_parts, v_pt), None, None, None, None, None, None
+        return dq, assemble(dk_parts, k_pt), assemble(dv_parts, v_pt), None, None, None, None, None, None, None
 
 
 def long_scaledot_attention(q_pt: torch.Tensor, k_pt: torch.Tensor, v_pt: torch.Tensor, n_keys: int, n_queries: int,
                             r: int, scale: float, k_tr: Optional[torch.Tensor] = None,
-                            v_tr: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``softmax(scale * q K^T) V`` on PT32 tensors (queries [B, T, r], keys / values [B, C, r]) for any
-    number of keys; returns the PT32 context vectors [B, T, r].  ``k_tr`` / ``v_tr``: optional
-    feature-major copies of keys / values (``Chain.store_tr``)."""
-    if r > L.NPF_MAX_FUSED_ROW:
-        raise NotImplementedError(f"attention over {r}-wide keys: the HIP path keeps at most "
+                            v_tr: Optional[torch.Tensor] = None, d: Optional[int] = None) -> torch.Tensor:
+    """``softmax(scale * q K^T) V`` on PT32 tensors (queries [B, T, d], keys [B, C, d], values [B, C, r]) for any
+    number of keys; returns the PT32 context vectors [B, T, r].  ``d``: width of keys and queries (default r);
+    ``k_tr`` / ``v_tr``: optional feature-major copies of keys / values (``Chain.store_tr``)."""
+    d = r if d is None else d
+    if max(r, d) > L.NPF_MAX_FUSED_ROW:
+        raise NotImplementedError(f"attention over {max(r, d)}-wide keys / values: the HIP path keeps at most "
                                   f"{L.NPF_MAX_FUSED_ROW} features per point in training")
-    if k_pt.shape[1] != tiles_of(n_keys) or pad32(r) // 4 != k_pt.shape[2]:
-        raise ValueError("keys tensor does not match (n_keys, r)")
-    return _LongScaledDot.apply(q_pt, k_pt, v_pt, n_keys, n_queries, r, float(scale), k_tr, v_tr)
+    if k_pt.shape[1] != tiles_of(n_keys) or pad32(d) // 4 != k_pt.shape[2]:
+        raise ValueError("keys tensor does not match (n_keys, d)")
+    if v_pt.shape[1] != tiles_of(n_keys) or pad32(r) // 4 != v_pt.shape[2]:
+        raise ValueError("values tensor does not match (n_keys, r)")
+    return _LongScaledDot.apply(q_pt, k_pt, v_pt, n_keys, n_queries, r, float(scale), k_tr, v_tr, d)

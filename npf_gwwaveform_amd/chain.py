@@ -560,12 +560,15 @@ class Chain:
     # ---- layers
     def linear(self, W: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
                addend: Optional[torch.Tensor] = None, addend_modulus: int = 0,
-               bias_per_task: bool = False, addend_rm: bool = False) -> "Chain":
-        """cur <- act(W cur + b [+ addend]).  ``W`` [N, K] may be a column slice of a wider
+               bias_per_task: bool = False, addend_rm: bool = False, residual: bool = False) -> "Chain":
+        """cur <- act(W cur + b [+ addend]) [+ cur].  ``W`` [N, K] may be a column slice of a wider
         matrix (row stride = ``W.stride(0)``); ``bias_per_task``: ``b`` is [n_tasks, pad32(N)];
         ``addend_rm``: the addend is a row-major [n_tasks (or modulus), pts, N] tensor (N % 32 == 0,
-        inference only)."""
+        inference only); ``residual``: the layer's input is added to its activated output (the hidden
+        layers of an ``MLP(is_res=True)``, mlp.py:100-104)."""
         N, K = W.shape
+        if residual and N != K:
+            raise ValueError(f"a residual layer keeps its width, got {K} -> {N}")
         if addend_rm and (addend is None or N % 32 or not addend.is_contiguous() or addend.shape[-1] != N):
             raise ValueError("a row-major addend must be contiguous with N % 32 == 0 features")
         if K != self.F:
@@ -579,7 +582,7 @@ class Chain:
             raise ValueError("per-task biases need wg_per_task=True")
         self.steps.append(_Step("linear", {"W": self._t(W), "b": self._t(b), "add": self._t(addend)},
                                 {"N": N, "K": K, "relu": relu, "mod": addend_modulus, "bpt": bias_per_task,
-                                 "add_rm": addend_rm}))
+                                 "add_rm": addend_rm, "res": residual}))
         self.F = N
         return self
 
@@ -760,6 +763,8 @@ class _ChainFn(torch.autograd.Function):
                 upstream = False
             elif k == "linear":
                 W, b, add = st.t["W"], st.t["b"], st.t["add"]
+                # residual layer: its input has to be in HBM (fp32) to come back after the activation
+                res_in = ensure_saved(a["K"]) if a.get("res") else None
                 if train and (needs_grad[W] or (b >= 0 and needs_grad[b])):
                     saved[(i, "in")] = ensure_saved(a["K"], internal=True)
                 if a.get("add_rm") and train and (upstream or needs_grad[W] or needs_grad[add]):
@@ -779,6 +784,9 @@ class _ChainFn(torch.autograd.Function):
                 upstream = upstream or needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if train and a["relu"] and upstream:
                     save_relu_mask(i, a["N"])
+                if res_in is not None:
+                    prog.add_pt(res_in, a["N"])
+                    backed = backed16 = None
             elif k == "add_pt":
                 prog.add_pt(T[st.t["x"]], a["F"], a["relu"], a["mod"])
                 backed = backed16 = None
@@ -932,6 +940,12 @@ class _ChainFn(torch.autograd.Function):
                 continue  # no gradient reaches this step
             if k == "linear":
                 W, b, add = st.t["W"], st.t["b"], st.t["add"]
+                g_res = None
+                if a.get("res") and upstream_before[i]:
+                    # y = act(W x + b) + x: the incoming gradient also reaches x directly; park it while cur goes
+                    # through the mask and W^T (the same wave reads back the addresses it wrote)
+                    g_res = new_pt(a["N"])
+                    prog.store_pt(g_res, a["N"])
                 if a["relu"]:
                     relu_backward(i, a["N"])
                 need_dz = needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
@@ -957,6 +971,8 @@ class _ChainFn(torch.autograd.Function):
                         prog.linear_bf16(w_t[(i, W)], 256 if padded else a["N"], a["K"], true_K=a["N"] if padded else None)
                     else:
                         prog.linear(w_t[(i, W)], a["N"], a["K"])  # W^T [K, N]
+                    if g_res is not None:
+                        prog.add_pt(g_res, a["K"])
                 else:
                     started = False  # nothing upstream needs this gradient
                     break

@@ -10,9 +10,9 @@ Mirrors (constructor kwargs, method names, return values, ``state_dict`` keys):
 (x-encoder, xy-encoder, [attention + merge +] decoder, Gaussian head); the stage methods
 (``encode_globally``, ``trgt_dependent_representation``, ``latent_path``, ``decode``) keep
 the reference's row-major signatures and run the same kernels stage by stage.
-Only the stock architecture is supported (MLP x-encoder, sum-merge MLP xy-encoder/decoder,
-``attention="scaledot"``); anything else raises ``NotImplementedError`` -- there is no
-fallback path.
+The reference's building blocks are supported (MLP x-encoder incl. ``is_res``, sum- or concatenating-merge
+MLP xy-encoder / decoder, ``x_transf_dim`` != ``r_dim``, ``attention`` = scaledot / multihead / transformer);
+anything else raises ``NotImplementedError`` -- there is no fallback path.
 """
 from __future__ import annotations
 
@@ -28,7 +28,7 @@ from torch.distributions import Independent, Normal
 from . import functional as FN
 from .architectures import (MLP, DotAttender, MergeFlatInputs, MultiheadAttender, SelfAttention, get_attender,
                             merge_flat_input)
-from .chain import Chain, PTensor, pad32
+from .chain import Chain, PTensor, pad32, pt_shape
 
 __all__ = ["NeuralProcessFamily", "LatentNeuralProcessFamily", "CNP", "LNP", "AttnCNP", "AttnLNP",
            "MultivariateNormalDiag", "HeadDistribution"]
@@ -109,8 +109,6 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         self.decoder = Decoder(self.x_transf_dim, self.r_dim, self.y_dim * 2)
         if not isinstance(self.x_encoder, MLP) or not isinstance(self.decoder, MergeFlatInputs):
             raise NotImplementedError("the HIP path needs the stock MLP XEncoder and merge_flat_input(MLP) Decoder")
-        if self.x_transf_dim != self.r_dim:
-            raise NotImplementedError("x_transf_dim != r_dim is not on the hot path")
         if max(self.x_dim, 2 * self.y_dim) > 32:
             raise NotImplementedError("x_dim and 2*y_dim are limited to 32 on the hot path")
         self.PredictiveDistribution = PredictiveDistribution
@@ -205,14 +203,9 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         """decoder(X_trgt_enc, R_trgt) when R_trgt is one vector per (z-sample, task)
         (np.py:107-110,161: the reference expands it over the targets and recomputes the
         resizer per target; here the resizer runs once per task)."""
-        resized = self.decoder.resizer(vec)  # [n_rows, r]
-        Fp = pad32(self.r_dim)
-        if resized.shape[1] != Fp:
-            resized = torch.nn.functional.pad(resized, (0, Fp - resized.shape[1]))
         ch = Chain(n_rows, T, Xt_pt.t.device)
         ch.input_pt(Xt_pt.t, self.x_transf_dim, modulus=(B if n_rows != B else 0))
-        ch.add_taskvec(resized.contiguous(), relu=True)
-        self.decoder.flat_module.append_to(ch).output_rows()
+        self.decoder.append_taskvec_to(ch, vec).output_rows()
         return ch.run()[0]
 
     # ------------------------------------------------------------------ reference stage API (row-major)
@@ -485,7 +478,7 @@ class AttnCNP(NeuralProcessFamily):
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
         ch = Chain(B, T, Xt_pt.t.device, wg_per_task=True)
         if C == 0:
-            ch.input_pt(torch.zeros_like(Xt_pt.t), self.r_dim)
+            ch.input_pt(torch.zeros(pt_shape(B, T, self.r_dim), device=Xt_pt.t.device), self.r_dim)
         else:
             self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
         self.decoder.append_to(ch, x1_pt=Xt_pt.t).output_rows()
@@ -538,13 +531,13 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
         if n_z == 1:
             ch = Chain(B, T, dev, wg_per_task=True)
             if C == 0:
-                ch.input_pt(torch.zeros_like(Xt_pt.t), r)
+                ch.input_pt(torch.zeros(pt_shape(B, T, r), device=dev), r)
             else:
                 self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
             mod = 0
         else:
             if C == 0:
-                R_det = torch.zeros_like(Xt_pt.t)
+                R_det = torch.zeros(pt_shape(B, T, r), device=dev)
             else:
                 cha = Chain(B, T, dev, wg_per_task=True)
                 self._attend_into(cha, Xc_pt, R, Xt_pt, C, T).output_pt()

@@ -55,6 +55,11 @@ class OracleConfig:
     z_dim: Optional[int] = None
     attention: str = "scaledot"  # attentive kinds: "scaledot" | "multihead" | "transformer" (attention.py:16-86)
     n_heads: int = 8
+    x_transf_dim: Optional[int] = None   # width of the encoded x (base.py:126-131); default r_dim
+    is_sum_merge: bool = True            # XY-encoder merge flavour (encoders.py:163-183; False = cat(x, y) -> MLP.  The
+                                         # reference's concatenating merge cannot serve as a decoder: its torch.cat of a
+                                         # 3-d X_trgt and a 4-d R_trgt raises, encoders.py:181)
+    is_res: bool = False                 # residual hidden layers in the XY-encoder / decoder flat MLPs (mlp.py:100-104)
 
     def __post_init__(self):
         if self.kind not in MODEL_KINDS:
@@ -70,6 +75,8 @@ class OracleConfig:
             }[self.kind]
         if self.z_dim is None:
             self.z_dim = self.r_dim
+        if self.x_transf_dim is None:
+            self.x_transf_dim = self.r_dim
 
     @property
     def is_latent(self) -> bool:
@@ -190,25 +197,38 @@ def _relu(v: torch.Tensor) -> torch.Tensor:
     return torch.relu(v)
 
 
-def mlp(params: Params, prefix: str, x: torch.Tensor, out_db_rounded: bool = True) -> torch.Tensor:
-    """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU, no dropout, no
-    residual: to_hidden -> relu -> [linears.i -> relu]* -> out (no activation).
+def mlp(params: Params, prefix: str, x: torch.Tensor, out_db_rounded: bool = True, is_res: bool = False) -> torch.Tensor:
+    """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU, no dropout:
+    to_hidden -> relu -> [linears.i -> relu (+ its input when ``is_res``, :103-104)]* -> out (no activation).
     (``out_db_rounded``: bf16 emulation only, see ``_LinearBf16``.)"""
     h = _relu(linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
     i = 0
     while f"{prefix}.linears.{i}.weight" in params:
-        h = _relu(linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
+        o = _relu(linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
+        h = o + h if is_res else o
         i += 1
     return linear(h, params[f"{prefix}.out.weight"], params[f"{prefix}.out.bias"], out_db_rounded)
 
 
-def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor, fused_addend: bool = True) -> torch.Tensor:
+def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor, fused_addend: bool = True,
+                   is_res: bool = False) -> torch.Tensor:
     """``MergeFlatInputs.forward`` with ``is_sum_merge=True``
     (npf/architectures/encoders.py:175-183): flat(relu(x1 + resizer(x2))).
     (``fused_addend``: bf16 emulation only -- x1 enters the resizer's last layer as its addend inside one
     chain, whose dZ buffer is then an fp32 tensor.)"""
     x2 = mlp(params, f"{prefix}.resizer", x2, out_db_rounded=not fused_addend)
-    return mlp(params, f"{prefix}.flat_module", _relu(x1 + x2))
+    return mlp(params, f"{prefix}.flat_module", _relu(x1 + x2), is_res=is_res)
+
+
+def merge_flat(cfg: "OracleConfig", params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """``MergeFlatInputs.forward`` (encoders.py:175-183) in the configured flavour: the sum merge above, or
+    ``flat(cat(x1, x2))`` (:180-181; x1 broadcast over the leading dims of x2 like the sum would)."""
+    if cfg.is_sum_merge:
+        return merge_flat_sum(params, prefix, x1, x2, is_res=cfg.is_res)
+    if MATMUL_MODE == "bf16":
+        raise NotImplementedError("the bf16 emulation models the sum-merge path only")
+    x1 = x1.expand(*x2.shape[:-1], x1.shape[-1])
+    return mlp(params, f"{prefix}.flat_module", torch.cat((x1, x2), dim=-1), is_res=cfg.is_res)
 
 
 def scaledot_attend(keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
@@ -286,8 +306,8 @@ def encode_globally(cfg: OracleConfig, params: Params, X_enc: torch.Tensor, Y: t
     if cfg.is_attentive:
         if C == 0:
             return torch.zeros(B, 0, cfg.r_dim)
-        return merge_flat_sum(params, "xy_encoder", X_enc, Y)
-    R_cntxt = merge_flat_sum(params, "xy_encoder", X_enc, Y)
+        return merge_flat(cfg, params, "xy_encoder", X_enc, Y)
+    R_cntxt = merge_flat(cfg, params, "xy_encoder", X_enc, Y)
     R = torch.mean(R_cntxt, dim=1, keepdim=True)
     if C == 0:
         R = torch.zeros(B, 1, cfg.r_dim)
@@ -365,9 +385,9 @@ def decode(cfg: OracleConfig, params: Params, Xt_enc: torch.Tensor, R_trgt: torc
         # mean-aggregation models: R_trgt is one vector per (sample, task) expanded over the targets; the HIP
         # path resizes it once per task (its own small chain) and adds the result to every target in fp32
         x2 = mlp(params, "decoder.resizer", R_trgt[..., :1, :])
-        suff = mlp(params, "decoder.flat_module", _relu(Xt_enc + x2))
+        suff = mlp(params, "decoder.flat_module", _relu(Xt_enc + x2), is_res=cfg.is_res)
     else:
-        suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt)
+        suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt, is_res=cfg.is_res)
     loc, raw = suff.split(cfg.y_dim, dim=-1)
     scale = p_y_scale_transform(raw)
     if not cfg.is_heteroskedastic:
@@ -530,12 +550,15 @@ def mlp_shapes(prefix: str, n_in: int, n_out: int, hidden: int, n_hidden_layers:
 def model_shapes(cfg: OracleConfig, n_layers_xy: int = 2, n_layers_dec: int = 4):
     """(name, out_features, in_features) for every Linear of the stock model, in the
     reference's state_dict order (base.py:143-146,157-175; np.py:62-82; base.py:447-458)."""
-    r, dx, dy = cfg.r_dim, cfg.x_dim, cfg.y_dim
-    shapes = mlp_shapes("x_encoder", dx, r, r, 1)
-    shapes += mlp_shapes("decoder.resizer", r, r, 32, 1)
-    shapes += mlp_shapes("decoder.flat_module", r, 2 * dy, r, n_layers_dec)
-    shapes += mlp_shapes("xy_encoder.resizer", dy, r, 32, 1)
-    shapes += mlp_shapes("xy_encoder.flat_module", r, r, r, n_layers_xy, force_smaller=True)
+    r, dx, dy, xt = cfg.r_dim, cfg.x_dim, cfg.y_dim, cfg.x_transf_dim
+    shapes = mlp_shapes("x_encoder", dx, xt, r, 1)
+    shapes += mlp_shapes("decoder.resizer", r, xt, 32, 1)
+    shapes += mlp_shapes("decoder.flat_module", xt, 2 * dy, r, n_layers_dec)
+    if cfg.is_sum_merge:
+        shapes += mlp_shapes("xy_encoder.resizer", dy, xt, 32, 1)
+        shapes += mlp_shapes("xy_encoder.flat_module", xt, r, r, n_layers_xy, force_smaller=True)
+    else:  # encoders.py:163-173: no resizer, the flat module takes cat(x, y)
+        shapes += mlp_shapes("xy_encoder.flat_module", xt + dy, r, r, n_layers_xy, force_smaller=True)
     if cfg.is_attentive and cfg.attention == "transformer":
         shapes += mlp_shapes("attender.mlp", r, r, r, 1)  # attention.py:556-561
     if cfg.is_latent:

@@ -55,14 +55,17 @@ def _latent_dist(loc, scale):
 
 def build_reference(case: dict):
     r = case["r"]
+    sm, res = case.get("is_sum_merge", True), case.get("is_res", False)
     kw = dict(
         r_dim=r,
         is_heteroskedastic=case.get("is_heteroskedastic", True),
         XYEncoder=merge_flat_input(
-            partial(MLP, n_hidden_layers=case["L_xy"], is_force_hid_smaller=True, hidden_size=r), is_sum_merge=True
+            partial(MLP, n_hidden_layers=case["L_xy"], is_force_hid_smaller=True, hidden_size=r, is_res=res), is_sum_merge=sm
         ),
-        Decoder=merge_flat_input(partial(MLP, n_hidden_layers=case["L_dec"], hidden_size=r), is_sum_merge=True),
+        Decoder=merge_flat_input(partial(MLP, n_hidden_layers=case["L_dec"], hidden_size=r, is_res=res), is_sum_merge=True),
     )
+    if "x_transf_dim" in case:
+        kw["x_transf_dim"] = case["x_transf_dim"]
     kind = case["kind"]
     if kind in ("LNP", "AttnLNP"):
         n_z = case.get("n_z", 1)
@@ -84,12 +87,24 @@ def ref_loss(case: dict):
             "sumo": npf.SUMOLossLNPF}[specs.loss_name(case)]()
 
 
-def run_case(name: str, case: dict, store_params: bool, store_full_grads: bool, adam_step: bool = False):
-    params = specs.make_params(case)
+def run_case(name: str, case: dict, store_params: bool, store_full_grads: bool, adam_step: bool = False,
+             own_init: bool = False):
     inp = specs.make_inputs(case)
-    model = build_reference(case)
-    missing = model.load_state_dict(params, strict=True)
-    assert not missing.missing_keys and not missing.unexpected_keys
+    if own_init:
+        # the reference's own (seeded) construction, biases moved off zero; stored in the fixture
+        torch.manual_seed(14)
+        model = build_reference(case)
+        rng = np.random.Generator(np.random.Philox(14))
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith(".bias"):
+                    p.copy_(torch.from_numpy(rng.uniform(-0.05, 0.05, tuple(p.shape)).astype("float32")))
+        params = {k: v.clone() for k, v in model.state_dict().items()}
+    else:
+        params = specs.make_params(case)
+        model = build_reference(case)
+        missing = model.load_state_dict(params, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
     model.train()
     if "eps" in inp:
         _EpsIndependent.eps = inp["eps"]
@@ -327,6 +342,9 @@ if __name__ == "__main__":
             run_selfattn_case()
         if any(o.startswith("g12") for o in only):
             run_eval_case()
+        for name, case in specs.VARIANT_CASES.items():
+            if any(name.startswith(o) for o in only):
+                run_case(name, case, store_params=True, store_full_grads=True, own_init=True)
         sys.exit(0)
     small_full = {"g1_cnp_c1", "g2_lnp_both_c1", "g2_lnp_latent_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64",
                   "g4s_attnlnp_r64_noqzcct"}
@@ -340,3 +358,5 @@ if __name__ == "__main__":
     run_pretrained_attn()
     run_selfattn_case()
     run_eval_case()
+    for name, case in specs.VARIANT_CASES.items():
+        run_case(name, case, store_params=True, store_full_grads=True, own_init=True)

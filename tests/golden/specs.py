@@ -65,6 +65,27 @@ CASES = {
                                    attention="transformer", is_q_zCct=True, n_z=2),
 }
 
+# G14: the reference's other MLP / merge options on the path's own files (mlp.py:100-104 ``is_res``, encoders.py:163-183
+# concatenating merge -- as XY-encoder: as a decoder the reference's own torch.cat of a 3-d and a 4-d tensor raises --,
+# base.py:126-131 ``x_transf_dim`` != ``r_dim``).  Parameters: the reference's own seeded
+# construction with perturbed biases, stored in the fixture (``param/...``).
+VARIANT_CASES = {
+    "g14_cnp_res": dict(kind="CNP", r=32, L_xy=3, L_dec=3, dx=1, dy=2, B=3, C=9, T=20, is_res=True),
+    "g14_attncnp_res": dict(kind="AttnCNP", r=64, L_xy=3, L_dec=4, dx=1, dy=2, B=2, C=20, T=45, is_res=True),
+    "g14_cnp_xt": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=2, dy=1, B=3, C=9, T=40, x_transf_dim=64),
+    "g14_lnp_xt": dict(kind="LNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=12, T=33, encoded_path="both", is_q_zCct=True,
+                       n_z=2, x_transf_dim=40),
+    "g14_attncnp_xt": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=17, T=40, x_transf_dim=32),
+    "g14_attnlnp_xt": dict(kind="AttnLNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=35, T=40, is_q_zCct=True, n_z=2,
+                           x_transf_dim=96),
+    "g14_cnp_cat": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=9, T=40, is_sum_merge=False),
+    "g14_lnp_cat": dict(kind="LNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=9, T=40, encoded_path="latent", n_z=3,
+                        is_sum_merge=False),
+    "g14_attncnp_cat": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=45, is_sum_merge=False),
+    "g14_attnlnp_all": dict(kind="AttnLNP", r=64, L_xy=3, L_dec=3, dx=1, dy=2, B=2, C=20, T=45, is_q_zCct=True, n_z=2,
+                            is_sum_merge=False, is_res=True, x_transf_dim=32),
+}
+
 # G12: evaluation protocol (utils/evaluate.py:9-28): 32 latent samples at test time, per-task log-likelihoods
 EVAL_CASES = {
     "attnlnp": dict(kind="AttnLNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=5, C=21, T=50, is_q_zCct=True, n_z=32),
@@ -81,7 +102,13 @@ def cfg_of(case: dict) -> O.OracleConfig:
         kind=case["kind"], x_dim=case["dx"], y_dim=case["dy"], r_dim=case["r"],
         encoded_path=case.get("encoded_path"), is_heteroskedastic=case.get("is_heteroskedastic", True),
         is_q_zCct=case.get("is_q_zCct", False), attention=case.get("attention", "scaledot"),
+        x_transf_dim=case.get("x_transf_dim"), is_sum_merge=case.get("is_sum_merge", True), is_res=case.get("is_res", False),
     )
+
+
+def golden_params(g: dict) -> dict:
+    """The ``param/...`` entries of a fixture as a state dict."""
+    return {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
 
 
 def make_params(case: dict, seed: int = 0):

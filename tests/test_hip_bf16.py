@@ -50,7 +50,9 @@ CASES.update({k: SWEEP[k] for k in ("cnp_r48", "cnp_r100_dx3_dy1", "cnp_r200_L1"
                                     "attncnp_r96", "attncnp_r160_c255", "attncnp_r256_c256_t100", "attncnp_r44",
                                     "attnlnp_nz3_r64", "attnlnp_nz2_r104_noq",
                                     # BASELINE config 3's model and point counts (batch 2): full gradients
-                                    "attncnp_c2_full", "attnlnp_c2_full")})
+                                    "attncnp_c2_full", "attnlnp_c2_full",
+                                    # residual layers on the ring pipeline, kq width != value width
+                                    "attncnp_r256_res", "attncnp_xt128_r256")})
 
 
 def _hip_bf16(case, inp, params):
@@ -76,8 +78,18 @@ def _hip_bf16(case, inp, params):
 @pytest.mark.parametrize("name", list(CASES))
 def test_bf16_mode_matches_the_bf16_oracle(name):
     case = CASES[name]
-    params = specs.make_params(case, seed=11)
-    inp = specs.make_inputs(case, seed=4321)
+    _gate(name, case, specs.make_params(case, seed=11), specs.make_inputs(case, seed=4321))
+
+
+@pytest.mark.parametrize("name", ["g14_cnp_res", "g14_attncnp_res", "g14_cnp_xt", "g14_lnp_xt", "g14_attncnp_xt", "g14_attnlnp_xt"])
+def test_bf16_mode_variants(name):
+    """Residual MLPs and x_transf_dim != r_dim in the bf16 compute mode (the residual itself is an fp32 add of the
+    layer's fp32 input on both sides), on the reference-constructed parameters of the G14 fixtures."""
+    case = specs.VARIANT_CASES[name]
+    _gate(name, case, specs.golden_params(specs.load_golden(name)), specs.make_inputs(case, seed=4321))
+
+
+def _gate(name, case, params, inp):
     ref_p, ref_out, ref_loss = _oracle(case, inp, params, mode="bf16")
     fp_p, fp_out, _ = _oracle(case, inp, params, mode="fp32")
     model, out, loss = _hip_bf16(case, inp, params)

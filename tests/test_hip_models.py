@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(case, train=True):
-    model = build_model(case, DEV)
+def _run(case, train=True, params=None):
+    model = build_model(case, DEV, params=params)
     inp = {k: v.to(DEV) for k, v in specs.make_inputs(case).items()}
     if "eps" in inp:
         EpsIndependent.eps = inp["eps"]
@@ -60,6 +60,30 @@ def test_model_train_step_parity(name):
             head = g[f"gradhead/{k}"]
             np.testing.assert_allclose(grad.reshape(-1)[:64].cpu().numpy(), head, rtol=1e-3,
                                        atol=1e-4 * np.abs(head).max() + 1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("name", list(specs.VARIANT_CASES))
+def test_model_variants_parity(name):
+    """G14: ``MLP(is_res=True)`` (mlp.py:100-104), the concatenating XY-encoder merge (encoders.py:180-181) and
+    ``x_transf_dim`` != ``r_dim`` (base.py:126-131) against the reference's outputs, loss, every gradient and its
+    evaluation-mode outputs -- on the parameters the reference constructed (stored in the fixture)."""
+    case = specs.VARIANT_CASES[name]
+    g = specs.load_golden(name)
+    model, out, loss = _run(case, params=specs.golden_params(g))
+    p_yCc, z_samples, q_zCc, q_zCct = out
+    assert_close(p_yCc.base_dist.loc, g["loc"], what="loc")
+    assert_close(p_yCc.base_dist.scale, g["scale"], what="scale")
+    np.testing.assert_allclose(p_yCc.base_dist.scale.detach().cpu().numpy(), g["scale"], rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=2e-5)
+    if "z_samples" in g:
+        assert_close(z_samples, g["z_samples"], what="z_samples")
+        assert_close(q_zCc.base_dist.scale, g["q_zCc_scale"], what="q_zCc.scale")
+    for k, p in model.named_parameters():
+        grad = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(grad, g[f"grad/{k}"], tol=1e-4, what=f"grad {k}")
+    _, out_e, _ = _run(case, train=False, params=specs.golden_params(g))
+    assert_close(out_e[0].base_dist.loc, g["eval_loc"], what="eval loc")
+    assert_close(out_e[0].base_dist.scale, g["eval_scale"], what="eval scale")
 
 
 @pytest.mark.parametrize("name", ["g1_cnp_c1", "g2_lnp_both_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64", "g6_cnp_homosk",

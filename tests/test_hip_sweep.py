@@ -46,6 +46,18 @@ SWEEP = {
                                  n_z=2),
     "attnlnp_c260_nz1_r32": dict(kind="AttnLNP", r=32, L_xy=1, L_dec=1, dx=1, dy=1, B=3, C=260, T=50, is_q_zCct=False,
                                  n_z=1),
+    # the reference's other MLP / merge options (G14 pins them on reference outputs) at the widths of the pipelined layers,
+    # of the 32-block instance, with the blocked attention and with unaligned weight-column slices
+    "attncnp_r256_res": dict(kind="AttnCNP", r=256, L_xy=3, L_dec=3, dx=1, dy=2, B=2, C=100, T=130, is_res=True),
+    "cnp_r512_res": dict(kind="CNP", r=512, L_xy=2, L_dec=3, dx=1, dy=2, B=2, C=33, T=70, is_res=True),
+    "attncnp_xt128_r256": dict(kind="AttnCNP", r=256, L_xy=2, L_dec=2, dx=1, dy=2, B=2, C=100, T=130, x_transf_dim=128),
+    "attncnp_xt64_r96_c300": dict(kind="AttnCNP", r=96, L_xy=1, L_dec=1, dx=1, dy=2, B=2, C=300, T=70, x_transf_dim=64),
+    "attncnp_cat_xt72_r96": dict(kind="AttnCNP", r=96, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=37, T=70, x_transf_dim=72,
+                                 is_sum_merge=False),
+    "attnlnp_cat_res_xt_r128": dict(kind="AttnLNP", r=128, L_xy=3, L_dec=3, dx=2, dy=3, B=2, C=40, T=48, is_q_zCct=True, n_z=2,
+                                    x_transf_dim=64, is_sum_merge=False, is_res=True),
+    "lnp_cat_nz2_r72": dict(kind="LNP", r=72, L_xy=2, L_dec=2, dx=2, dy=3, B=2, C=31, T=33, encoded_path="both",
+                            is_q_zCct=True, n_z=2, is_sum_merge=False),
     "attnlnp_nz2_r104_noq": dict(kind="AttnLNP", r=104, L_xy=1, L_dec=2, dx=1, dy=2, B=2, C=19, T=35, is_q_zCct=False,
                                  n_z=2),
 }

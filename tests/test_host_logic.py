@@ -182,8 +182,13 @@ def test_unsupported_configurations_fail_loudly():
         A.MLP(4, 4, activation=torch.nn.GELU())
     with pytest.raises(NotImplementedError):
         A.MLP(4, 4, dropout=0.1)
-    with pytest.raises(NotImplementedError):
-        A.merge_flat_input(A.MLP, is_sum_merge=False)(8, 2, 8)
+    cat = A.merge_flat_input(A.MLP, is_sum_merge=False)(8, 2, 8)   # concatenating merge: one MLP over x1 | x2
+    assert not hasattr(cat, "resizer") and cat.flat_module.to_hidden.in_features == 10
+    res = A.MLP(8, 8, hidden_size=8, n_hidden_layers=3, is_res=True)
+    assert res.is_res and len(res.linears) == 2
+    m = A.AttnCNP(1, 2, r_dim=64, x_transf_dim=32)                  # base.py:126-131
+    assert m.x_encoder.out.out_features == 32 and m.decoder.resizer.out.out_features == 32
+    assert m.xy_encoder.flat_module.to_hidden.in_features == 32 and m.attender.kq_size == 32
     with pytest.raises(NotImplementedError):
         A.CNP(1, 1, p_y_scale_transformer=lambda s: s)
 

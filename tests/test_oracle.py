@@ -15,9 +15,10 @@ BIG = [n for n, c in specs.CASES.items() if c["r"] >= 256]
 LOSSES = {"cnpf": O.cnpf_loss, "elbo": O.elbo_loss, "nll": O.nll_loss, "sumo": O.sumo_loss}
 
 
-def run_oracle(case, training=True, with_grad=True):
+def run_oracle(case, training=True, with_grad=True, params=None):
     cfg = specs.cfg_of(case)
-    params = {k: v.clone().requires_grad_(with_grad) for k, v in specs.make_params(case).items()}
+    params = specs.make_params(case) if params is None else params
+    params = {k: v.clone().requires_grad_(with_grad) for k, v in params.items()}
     inp = specs.make_inputs(case)
     out = O.forward(cfg, params, inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"],
                     inp["Y_trgt"] if training else None, eps=inp.get("eps"), n_z=case.get("n_z", 1),
@@ -50,6 +51,27 @@ def test_oracle_bit_exact_small(name):
         # gradients: same op sequence, same autograd formulas -> tight, but the loss
         # restatement sums in a slightly different association, so allow last-ulp noise
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6 * max(1e-30, np.abs(ref).max()), err_msg=k)
+
+
+@pytest.mark.parametrize("name", list(specs.VARIANT_CASES))
+def test_oracle_bit_exact_variants(name):
+    """G14: residual MLPs, the concatenating XY-encoder merge, x_transf_dim != r_dim -- on the parameters the
+    reference itself constructed (stored in the fixture)."""
+    case = specs.VARIANT_CASES[name]
+    g = specs.load_golden(name)
+    params, out, loss = run_oracle(case, params=specs.golden_params(g))
+    assert np.array_equal(out["loc"].detach().numpy(), g["loc"])
+    assert np.array_equal(out["scale"].detach().numpy(), g["scale"])
+    assert np.array_equal(loss.detach().numpy(), g["loss"])
+    if "z_samples" in g:
+        assert np.array_equal(out["z_samples"].detach().numpy(), g["z_samples"])
+    for k, p in params.items():
+        ref = g[f"grad/{k}"]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6 * max(1e-30, np.abs(ref).max()), err_msg=k)
+    _, out_e, _ = run_oracle(case, training=False, with_grad=False, params=specs.golden_params(g))
+    assert np.array_equal(out_e["loc"].detach().numpy(), g["eval_loc"])
+    assert np.array_equal(out_e["scale"].detach().numpy(), g["eval_scale"])
 
 
 @pytest.mark.parametrize("name", SMALL)
