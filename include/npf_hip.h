@@ -188,6 +188,11 @@ typedef struct npf_wgrad_job {
 #define NPF_WGRAD_BF16 2
 #define NPF_WGRAD_DZ16 4 /* with NPF_WGRAD_BF16: dZ is a PT16 tensor (bf16 tiles, see NPF_F_P16) */
 #define NPF_WGRAD_A16 8  /* with NPF_WGRAD_BF16: A is a PT16 tensor */
+/* fp32 result on the bf16 matrix pipe (all jobs of a launch alike, not with NPF_WGRAD_BF16): each fp32 operand is split
+ * exactly into three bf16 terms and six of the nine cross products are accumulated in fp32 -- the dropped terms are
+ * below 2^-26 of a product, i.e. under fp32 rounding; same operands, same result to summation-order noise, 6/16 of
+ * the v_mfma_f32_16x16x4_f32 time (csrc/wgrad_kernel.hip, wgrad_x6_kernel). */
+#define NPF_WGRAD_F32X6 16
 
 #define NPF_MAX_WGRAD_JOBS 16
 /* Runs up to NPF_MAX_WGRAD_JOBS jobs over the same points in ONE launch (+ one reduce). */

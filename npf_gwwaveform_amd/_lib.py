@@ -54,6 +54,7 @@ class NpfWgradJob(C.Structure):
 
 
 NPF_MAX_WGRAD_JOBS = 16
+WGRAD_F32X6 = 16              # npf_wgrad_job_t.accumulate bit: fp32 contraction as six bf16 products per term (NPF_WGRAD_F32X6)
 
 
 class NpfWprepJob(C.Structure):

@@ -37,6 +37,10 @@ MASK_BITS = os.environ.get("NPF_NO_MASK_BITS", "0") != "1"  # bf16 mode: ReLU ma
 PAD_SMALL_K = os.environ.get("NPF_NO_PAD_SMALL_K", "0") != "1"
 DUMP_PROGRAMS = os.environ.get("NPF_DUMP_PROGRAMS", "0") == "1"
 FUSE_STORES = os.environ.get("NPF_NO_FUSED_STORE", "0") != "1"  # bf16 mode: STORE_PT + LINEAR -> LINEAR | F_STORE_IN (debug switch)
+# fp32 mode: weight / key / value gradients on the bf16 matrix pipe -- every fp32 operand split exactly into three bf16
+# terms, six cross products accumulated in fp32 (NPF_WGRAD_F32X6: the result agrees with the v_mfma_f32_16x16x4_f32
+# kernel to fp32 summation-order noise, at 6/16 of its matrix-pipe time).  NPF_NO_WGRAD_X6=1: the native fp32 kernel.
+WGRAD_X6 = os.environ.get("NPF_NO_WGRAD_X6", "0") != "1"
 
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
@@ -448,7 +452,8 @@ def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
             arr[j].per_task = int(jb.get("per_task", False))
             # bit 1: bf16 products (bf16 compute mode: every weight / key / value gradient of the step)
             arr[j].accumulate = (int(jb.get("accumulate", False)) | (2 if COMPUTE_DTYPE == "bf16" else 0)
-                                 | (4 if z16 else 0) | (8 if a16 else 0))
+                                 | (4 if z16 else 0) | (8 if a16 else 0)
+                                 | (L.WGRAD_F32X6 if WGRAD_X6 and COMPUTE_DTYPE != "bf16" else 0))
         nbytes = lib.npf_wgrad_partials_bytes(arr, len(chunk), n_tasks, tiles_of(pts))
         if nbytes < 0:
             raise RuntimeError("npf_wgrad_partials_bytes: invalid wgrad jobs")

@@ -418,6 +418,316 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 contraction on the bf16 matrix pipe (NPF_WGRAD_F32X6).  gfx950 multiplies fp32 at 1/16 of its bf16 rate
+// (v_mfma_f32_16x16x4_f32: 32 cycles for 2 KFLOP; v_mfma_f32_16x16x32_bf16: 16 cycles for 16 KFLOP), so an fp32
+// product is cheaper as SIX bf16 products: every fp32 operand is split EXACTLY into three bf16 terms
+//   x = x0 + x1 + x2 (+ r, |r| <= 2^-27 |x|):  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
+// (round-to-nearest-even each time; the two subtractions are exact in fp32), and of the nine cross products of
+// a * b the six with i + j <= 2 are accumulated in fp32 by the MFMA (a bf16 x bf16 product is exact in fp32); the
+// dropped ones are below 2^-26 |a b|, under the fp32 rounding of the product itself.  Same contraction, same fp32
+// PT32 operands in HBM, same result to fp32 summation-order noise (measured: closer to float64 than the fp32 MFMA
+// kernel) -- at 6/16 of the matrix-pipe time.
+//
+// Front end = the fp32 kernel's: tiles by LDS-DMA into a double-buffered swizzled fp32 image, one barrier per tile.
+// Workgroup = 8 waves (2 per SIMD, up to 256 registers each), wave (rg, cp) owns the 64 x 128 block of dW made of row
+// block rg and column blocks 2 cp, 2 cp + 1 (128 accumulator registers).  The split happens in registers at the
+// fragment read.  dZ side: the lane's quad row at its 8 points (4 g + j, 16 + 4 g + j = the k-slots of
+// v_mfma_f32_16x16x32_bf16; 8 x ds_read_b128) once per tile, all four operands m split (48 registers).  A side: per
+// step (column block, operand n2) one feature at the 8 points (8 x ds_read_b32), read two steps ahead, split one step
+// ahead with its ~50 vector instructions dealt two per MFMA between the 24 MFMAs of the running step; the next
+// tile's DMA pieces go out one per step.
+// What was measured on the way (7 jobs of 256 x 256 over 262 144 points; fp32 kernel 1.85 ms, HBM floor 0.64 ms):
+// a version that split each tile ONCE into three bf16 images in LDS (96 KiB, single-buffered: the 160 KiB do not hold
+// two sets) needed two barriers and a vector-only phase per tile: 1.55 ms; splitting at the read with the compiler's
+// lowering of __builtin_convertvector (16 instructions per pair) 1.58, hand-written (11) 1.47, interleaved with the
+// MFMAs and with the DMA issue spread 1.38.  With zeros in LDS (no DMA) the same code runs 1.05: the rest is the
+// clock the chip holds with real operands on the bf16 pipe.
+constexpr int kXThreads = 512;
+constexpr int kXWaves = kXThreads / 64;
+
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+struct X6Terms { bf16x8w t[3]; };
+
+// Eleven vector instructions per pair of values (hipcc's lowering of the same arithmetic written with
+// __builtin_convertvector takes sixteen: it converts element by element): RNE to bf16 (packed), both halves back to
+// fp32 (shift / mask), exact remainders, twice.
+__device__ __forceinline__ unsigned x6_cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ X6Terms x6_split(f32x8v v) {
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v t0, t1, t2;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = v[2 * p], b = v[2 * p + 1];
+    const unsigned h = x6_cvt_pk(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = x6_cvt_pk(ra, rb);
+    const float la = ra - __builtin_bit_cast(float, m << 16), lb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    t0[p] = h;
+    t1[p] = m;
+    t2[p] = x6_cvt_pk(la, lb);
+  }
+  X6Terms o;
+  o.t[0] = __builtin_bit_cast(bf16x8w, t0);
+  o.t[1] = __builtin_bit_cast(bf16x8w, t1);
+  o.t[2] = __builtin_bit_cast(bf16x8w, t2);
+  return o;
+}
+
+struct X6Raw { f32x4 q[8]; };  // quad row of the lane at its 8 points: q[4 h + j] = point 16 h + 4 g + j
+__device__ __forceinline__ void x6_issue(const unsigned (&ad)[4], X6Raw& r) {
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+               "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %9 offset:256\n\t"
+               "ds_read_b128 %6, %10 offset:256\n\tds_read_b128 %7, %11 offset:256"
+               : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.q[3]), "=&v"(r.q[4]), "=&v"(r.q[5]), "=&v"(r.q[6]),
+                 "=&v"(r.q[7])
+               : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]));
+}
+// One feature of the lane's quad row at its 8 points (ds_read_b32 x 8; ad[j] already carries the feature's byte offset;
+// SEL: column block + SEL).  The feature a lane takes at step n2 is n2 ^ 2 ((i >> 3) & 1): lanes i and i + 8 would hit
+// the same banks with the same feature (4-way conflict with the g / g + 1 pair; this leaves 2-way).
+struct X6Feat { float v[8]; };
+template <int SEL>
+__device__ __forceinline__ void x6_issue_feat(const unsigned (&ad)[4], X6Feat& r) {
+  asm volatile("ds_read_b32 %0, %8 offset:%12\n\tds_read_b32 %1, %9 offset:%12\n\t"
+               "ds_read_b32 %2, %10 offset:%12\n\tds_read_b32 %3, %11 offset:%12\n\t"
+               "ds_read_b32 %4, %8 offset:%13\n\tds_read_b32 %5, %9 offset:%13\n\t"
+               "ds_read_b32 %6, %10 offset:%13\n\tds_read_b32 %7, %11 offset:%13"
+               : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]),
+                 "=&v"(r.v[7])
+               : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "n"(SEL * 8192), "n"(SEL * 8192 + 256));
+}
+// wait until at most N LDS operations of this wave are outstanding (they retire in order)
+template <int N>
+__device__ __forceinline__ void x6_wait_feat(X6Feat& r) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7])
+               : "n"(N));
+}
+__device__ __forceinline__ X6Terms x6_terms_of(const X6Feat& r) {
+  return x6_split(f32x8v{r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], r.v[6], r.v[7]});
+}
+__device__ __forceinline__ void x6_wait(X6Raw& r) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]), "+v"(r.q[4]), "+v"(r.q[5]), "+v"(r.q[6]), "+v"(r.q[7]));
+}
+__device__ __forceinline__ X6Terms x6_terms_of(const X6Raw& r, int f) {
+  const f32x8v v = {r.q[0][f], r.q[1][f], r.q[2][f], r.q[3][f], r.q[4][f], r.q[5][f], r.q[6][f], r.q[7][f]};
+  return x6_split(v);
+}
+
+__global__ __launch_bounds__(kXThreads, 1) void wgrad_x6_kernel(const WgradJobs J, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kQRows * 128];  // 2 buffers x (dZ, A), as wgrad_kernel
+  constexpr int kOp = kQRows * 128;
+
+  int j = 0;
+  while (j + 1 < J.n_jobs && (int)blockIdx.x >= J.first_wg[j + 1]) ++j;
+  const npf_wgrad_job_t& job = J.job[j];
+  const int split = blockIdx.x - J.first_wg[j];
+  const int n_split = J.first_wg[j + 1] - J.first_wg[j];
+  const int Np = ((job.N + 31) >> 5) * 32, Kp = ((job.K + 31) >> 5) * 32;
+  const long total_tiles = (long)J.n_tasks * J.tiles_per_task;
+  long t0, t1;
+  int tstride = 1;
+  if (job.per_task) {
+    t0 = (long)split * J.tiles_per_task;
+    t1 = t0 + J.tiles_per_task;
+  } else {
+    t0 = split;
+    t1 = total_tiles;
+    tstride = n_split;
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave >> 1, cp = wave & 1;
+  const bool act_r = 64 * rg < Np && 128 * cp < Kp;
+  const int n_steps = !act_r ? 0 : (64 * (2 * cp + 1) < Kp ? 8 : 4);  // (column block, operand) steps with data
+
+  for (int x = tid; x < 2 * 2 * kOp; x += kXThreads) lds[x] = 0.f;  // quad rows beyond Np / 4, Kp / 4 stay zero
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[c][m][n] = zero4;
+  f32x4 dbacc = zero4;
+
+  // DMA as in wgrad_kernel, pieces dealt to 8 waves (q = wave + 8 n: the swizzle term (2 q + h) & 15 = (2 wave + h) & 15)
+  const unsigned dma_lane = 4u * (unsigned)((lane >> 5) * 128 + (((lane & 31) ^ ((2 * wave + (lane >> 5)) & 15)) << 2));
+  const char* dz_base = (const char*)job.dZ;
+  const char* a_base = (const char*)job.A;
+  asm volatile("" : "+s"(dz_base), "+s"(a_base));
+  const int Zf = job.ldz > 0 ? job.ldz : Np, Af = job.lda > 0 ? job.lda : Kp;
+  auto tile_dma = [&](long t, float* buf) {
+    const char* zsrc = dz_base + (size_t)t * Zf * 128;
+    const char* asrc = a_base + (size_t)t * Af * 128;
+    for (int q = wave; q < (Np >> 3); q += kXWaves)
+      wg_dma16((const float*)(zsrc + (size_t)q * 1024 + (size_t)dma_lane), buf + q * 256);
+    for (int q = wave; q < (Kp >> 3); q += kXWaves)
+      wg_dma16((const float*)(asrc + (size_t)q * 1024 + (size_t)dma_lane), buf + kOp + q * 256);
+  };
+
+  __syncthreads();
+  if (t0 < t1) tile_dma(t0, lds);
+
+  int cur = 1;
+  for (long t = t0; t < t1; t += tstride) {
+    cur ^= 1;
+    __syncthreads();  // vmcnt(0): tile t has landed; everyone is done with the other buffer
+    // the next tile's DMA: a wave without work issues its (up to eight) pieces here, the others one per step below
+    // (an LDS-DMA instruction costs its wave 60 - 180 cycles of issue: eight in a row ahead of the tile's first MFMA
+    // showed up one for one in the tile time)
+    const bool dma_next = t + tstride < t1;
+    float* nbuf = lds + (cur ^ 1) * 2 * kOp;
+    if (n_steps == 0) {
+      if (dma_next) tile_dma(t + tstride, nbuf);
+      continue;
+    }
+    const char* zsrc_n = dz_base + (size_t)(t + tstride) * Zf * 128 + (size_t)dma_lane;
+    const char* asrc_n = a_base + (size_t)(t + tstride) * Af * 128 + (size_t)dma_lane;
+    // fragment addresses (per tile, from an opaque copy of the lane ids: hoisted out of the loop they would be spilled,
+    // and a spill reload waits on vmcnt, i.e. on the tile DMA just issued): chunk (4 g + j) ^ i of the lane's quad row;
+    // the points 16 + .. are 256 bytes further, column block 2 cp + 1 is 8 KiB further
+    int iv = i, gv = g;
+    asm volatile("" : "+v"(iv), "+v"(gv));
+    unsigned za[4], zb[4];
+    {
+      const unsigned l0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds + cur * 2 * kOp * 4;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const unsigned lanepart = (unsigned)(((4 * gv + jj) ^ iv) << 4);
+        za[jj] = l0 + (16 * rg + iv) * 512 + lanepart;
+        zb[jj] = l0 + kOp * 4 + (32 * cp + iv) * 512 + lanepart;
+      }
+    }
+    X6Raw ra;
+    x6_issue(za, ra);
+    x6_wait(ra);
+    if (cp == 0) dbacc += ((ra.q[0] + ra.q[1]) + (ra.q[2] + ra.q[3])) + ((ra.q[4] + ra.q[5]) + (ra.q[6] + ra.q[7]));
+    X6Terms fa[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fa[m] = x6_terms_of(ra, m);
+    // A side: per step k = (column block c = k >> 2, operand n2 = k & 3) one feature of the lane's quad row, n2 ^ pi with
+    // pi = 2 ((i >> 3) & 1), read TWO steps ahead (8 registers per step in flight) and split ONE step ahead, its ~50
+    // vector instructions dealt between the 24 MFMAs of the running step (sched_group_barrier)
+    const unsigned pi4 = (unsigned)((iv >> 3) & 1) << 3;  // 4 * pi
+    auto feat_addr = [&](int n2, unsigned (&ad)[4]) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) ad[jj] = zb[jj] + ((4u * (unsigned)n2) ^ pi4);
+    };
+    X6Feat raw[2];
+    {
+      unsigned ad[4];
+      feat_addr(0, ad);
+      x6_issue_feat<0>(ad, raw[0]);
+      feat_addr(1, ad);
+      x6_issue_feat<0>(ad, raw[1]);
+    }
+    x6_wait_feat<8>(raw[0]);
+    X6Terms fb = x6_terms_of(raw[0]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = k >> 2, n2 = k & 3;
+      if (dma_next) {  // piece wave + 8 (k & 3) of dZ (steps 0..3) / of A (steps 4..7)
+        const int q = wave + kXWaves * (k & 3);
+        if (k < 4) {
+          if (q < (Np >> 3)) wg_dma16((const float*)(zsrc_n + (size_t)q * 1024), nbuf + q * 256);
+        } else {
+          if (q < (Kp >> 3)) wg_dma16((const float*)(asrc_n + (size_t)q * 1024), nbuf + kOp + q * 256);
+        }
+      }
+      if (k + 2 < 8) {
+        unsigned ad[4];
+        feat_addr((k + 2) & 3, ad);
+        if (k + 2 < 4) x6_issue_feat<0>(ad, raw[k & 1]);
+        else x6_issue_feat<1>(ad, raw[k & 1]);
+      }
+      X6Terms fb_next;
+      if (k + 1 < 8) {
+        if (k + 2 < 8) x6_wait_feat<8>(raw[(k + 1) & 1]);
+        else x6_wait_feat<0>(raw[(k + 1) & 1]);
+        fb_next = x6_terms_of(raw[(k + 1) & 1]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        f32x4 a = acc[c][m][n2];
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m].t[2], fb.t[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m].t[0], fb.t[2], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m].t[1], fb.t[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m].t[1], fb.t[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m].t[0], fb.t[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m].t[0], fb.t[0], a, 0, 0, 0);
+        acc[c][m][n2] = a;
+      }
+      if (k + 1 < 8) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {  // one MFMA, two vector instructions, ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        fb = fb_next;
+      }
+    }
+  }
+
+  // ---- write out: acc[c][m][n][e] on lane (i, g) = D[row 4 (16 rg + 4 g + e) + m][col 4 (16 (2 cp + c) + i) + n] ----
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (4 * c >= n_steps) continue;
+    const int cg = 2 * cp + c;
+    const int col0 = 4 * (16 * cg + i);
+    if (job.per_task) {
+      const int Ko = job.ldo > 0 ? job.ldo : Kp;
+      float* out = job.dW + (size_t)split * ((size_t)(Np >> 5) * Ko * 32);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 4 * (16 * rg + 4 * g + e) + m;
+          if (row >= Np || col0 >= Kp) continue;
+          f32x4 v;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) v[n] = (i & 8) ? acc[c][m][n ^ 2][e] : acc[c][m][n][e];  // (lanes i >= 8: feature n2 ^ 2)
+          float* dst = out + (size_t)(row >> 5) * (Ko >> 2) * 128 + (row & 31) * 4 + (size_t)(col0 >> 2) * 128;
+          if (job.accumulate & NPF_WGRAD_ACCUMULATE) v += *(const f32x4*)dst;
+          *(f32x4*)dst = v;
+        }
+    } else {
+      float* part = partials + J.part_off[j] + (size_t)split * ((size_t)Np * Kp + Np);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 4 * (16 * rg + 4 * g + e) + m;
+          if (row >= Np || col0 >= Kp) continue;
+          f32x4 v;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) v[n] = (i & 8) ? acc[c][m][n ^ 2][e] : acc[c][m][n][e];
+          *(f32x4*)(part + (size_t)row * Kp + col0) = v;
+        }
+    }
+  }
+  if (!job.per_task && n_steps > 0 && cp == 0) {
+    // dbacc[m] on lane (i, g): sum over the lane's points of feature 4 (16 rg + i) + m
+    float* part = partials + J.part_off[j] + (size_t)split * ((size_t)Np * Kp + Np);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      dbacc[m] += __shfl_xor(dbacc[m], 16);
+      dbacc[m] += __shfl_xor(dbacc[m], 32);
+    }
+    if (g == 0 && 4 * (16 * rg + i) < Np) *(f32x4*)(part + (size_t)Np * Kp + 4 * (16 * rg + i)) = dbacc;
+  }
+}
+
 // dW[n][k] (+)= sum_s partial[s][n][k];  db[n] (+)= sum_s partial_db[s][n].
 // One float4 of the slab per thread, four independent accumulators over the splits (the sum is
 // latency-bound: each term is a separate 16-byte load from a different slab).
@@ -481,8 +791,11 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
   // (fp32 variant: the MFMAs set the tile time.)  The bf16 variant has 1/8 of the MFMA cycles and its tile
   // time follows the bytes of the tile plus a latency floor (one tile in flight per workgroup): a skinny job
   // costs almost as much per tile as a square one, and priced by its MFMAs it becomes the launch's critical path.
-  bool bf16 = true;
-  for (int j = 0; j < n_jobs; ++j) bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
+  bool bf16 = true, x6 = true;
+  for (int j = 0; j < n_jobs; ++j) {
+    bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
+    x6 &= (jobs[j].accumulate & (NPF_WGRAD_F32X6 | NPF_WGRAD_BF16)) == NPF_WGRAD_F32X6;
+  }
   double cost[kMaxJobs], cost_sum = 0.0;
   for (int j = 0; j < n_jobs; ++j) {
     const int Np = npf::round_up(jobs[j].N, 32), Kp = npf::round_up(jobs[j].K, 32);
@@ -493,7 +806,14 @@ static int plan(const npf_wgrad_job_t* jobs, int n_jobs, int n_tasks, int tiles_
     const double bytes = 32.0 * (Np * zb + Kp * ab);
     if (jobs[j].per_task) cost[j] = 0.0;
     else if (bf16) cost[j] = bytes > 18432.0 ? bytes : 18432.0;
-    else {
+    else if (x6) {
+      // split kernel: a wave owns a 64 x 128 block and runs 192 MFMAs of 16 cycles per tile beside ~800 vector
+      // instructions (measured ~1.6 x the bare MFMA time on real data), two waves per SIMD when the job is square;
+      // plus the per-tile prologue (dZ-side reads and split, barrier); or the tile's bytes
+      const int waves = ar * ((ac + 1) / 2);
+      const double mf = 3072.0 * 1.6 * ((waves + 3) / 4) + 2500.0, mem = bytes / 6.5;
+      cost[j] = mf > mem ? mf : mem;
+    } else {
       const double mf = 4096.0 * (ar < ac ? ar : ac), mem = bytes / 6.5;
       cost[j] = mf > mem ? mf : mem;
     }
@@ -566,9 +886,14 @@ extern "C" int npf_wgrad_run(const npf_wgrad_job_t* jobs, int32_t n_jobs, int32_
   for (int j = 0; j < n_jobs; ++j) any_shared |= !jobs[j].per_task;
   if (any_shared && (!partials || partials_bytes < need || (((uintptr_t)partials) & 15))) return NPF_EINVAL;
   const int n_wg = J.first_wg[n_jobs];
-  bool bf16 = true;
-  for (int j = 0; j < n_jobs; ++j) bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
-  if (bf16)
+  bool bf16 = true, x6 = true;
+  for (int j = 0; j < n_jobs; ++j) {
+    bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
+    x6 &= (jobs[j].accumulate & (NPF_WGRAD_F32X6 | NPF_WGRAD_BF16)) == NPF_WGRAD_F32X6;
+  }
+  if (x6)
+    hipLaunchKernelGGL(npf::wgrad_x6_kernel, dim3(n_wg), dim3(npf::kXThreads), 0, (hipStream_t)stream, J, partials);
+  else if (bf16)
     hipLaunchKernelGGL(npf::wgrad_kernel<true>, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);
   else
     hipLaunchKernelGGL(npf::wgrad_kernel<false>, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);

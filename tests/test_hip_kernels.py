@@ -349,6 +349,63 @@ def test_bf16_wgrad_matches_bf16_emulation():
         assert_close(db, dz.double().sum((0, 1)), tol=1e-5, what="bf16 wgrad db")
 
 
+def test_wgrad_split_bf16_products_equal_fp32():
+    """NPF_WGRAD_F32X6 (wgrad_x6_kernel): the fp32 contraction with every operand split exactly into three bf16 terms and six
+    cross products per term on the bf16 matrix pipe.  Against a float64 contraction of the same fp32 operands -- entries
+    spread over six decades -- its error stays at the native fp32 kernel's (fp32 summation noise), far below one bf16 or
+    even one two-term (bf16 x 2) rounding; bias gradients, per-task (key / value) jobs, accumulation into dW, blocks of
+    operands wider than 256 features and widths that are not multiples of 32 included."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(47)
+
+    def operands(n_tasks, pts, N, K):
+        spread = lambda *sh: torch.randn(*sh, generator=g) * 10.0 ** (6 * torch.rand(*sh, generator=g) - 3)  # noqa: E731
+        return spread(n_tasks, pts, N), spread(n_tasks, pts, K)
+
+    def run(x6, jobs_of):
+        old = CH.WGRAD_X6
+        CH.WGRAD_X6 = x6
+        try:
+            return jobs_of()
+        finally:
+            CH.WGRAD_X6 = old
+
+    for n_tasks, pts, N, K in ((3, 70, 256, 256), (2, 45, 100, 36), (1, 200, 32, 256), (4, 33, 64, 2), (2, 300, 4, 256),
+                               (2, 64, 512, 384), (5, 31, 200, 130)):
+        dz, a = operands(n_tasks, pts, N, K)
+        ref = torch.einsum("bpn,bpk->nk", dz.double(), a.double())
+        mag = torch.einsum("bpn,bpk->nk", dz.double().abs(), a.double().abs())  # what fp32 noise scales with
+        ref_b = dz.double().sum((0, 1))
+        errs = {}
+        for x6 in (True, False):
+            def jobs_of():
+                dW0 = torch.randn(N, K, generator=g)
+                dW, db = dW0.to(DEV), torch.zeros(N, device=DEV)
+                CH.run_wgrad([dict(dZ=FN.pack_pt(dz.to(DEV)), A=FN.pack_pt(a.to(DEV)), N=N, K=K, dW=dW, db=db, accumulate=True)],
+                             n_tasks, pts, DEV)
+                return dW.cpu().double() - dW0.double(), db.cpu().double()
+            dW, db = run(x6, jobs_of)
+            errs[x6] = float(((dW - ref).abs() / mag).max())
+            assert float((db - ref_b).abs().max()) <= 2e-6 * float(dz.double().abs().sum((0, 1)).max()), (x6, N, K)
+        # relative to sum |dz| |a|: fp32 accumulation of ~n_tasks * pts terms; one bf16 rounding would be 4e-3, bf16 x 2 1.5e-5
+        assert errs[True] <= 2e-6, (N, K, errs)
+        assert errs[True] <= 4 * errs[False] + 2e-7, (N, K, errs)
+
+    # per-task jobs (attention: dK[c][d] = sum_t dS[t][c] q[t][d]) -> PT32 outputs
+    for n_tasks, pts, N, K in ((3, 130, 256, 256), (2, 64, 37, 96)):
+        dz, a = operands(n_tasks, pts, N, K)
+        ref = torch.einsum("bpn,bpk->bnk", dz.double(), a.double())
+        mag = torch.einsum("bpn,bpk->bnk", dz.double().abs(), a.double().abs())
+        for x6 in (True, False):
+            def jobs_of():
+                out = CH.pt_empty(n_tasks, N, K, DEV)
+                CH.run_wgrad([dict(dZ=FN.pack_pt(dz.to(DEV)), A=FN.pack_pt(a.to(DEV)), N=N, K=K, dW=out, per_task=True)],
+                             n_tasks, pts, DEV)
+                return FN.unpack_pt(out, N, K).cpu().double()
+            got = run(x6, jobs_of)
+            assert float(((got - ref).abs() / mag).max()) <= 2e-6, (x6, N, K)
+
+
 def _pack_pt16_reference(x):
     """Row-major [B, P, F] -> PT16 (bf16 tiles) with plain torch ops (the layout of chain.pt16_shape)."""
     B, P, F = x.shape
