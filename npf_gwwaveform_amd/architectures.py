@@ -7,9 +7,9 @@ Mirrors, for the hot path only:
                                 npf/architectures/encoders.py:130-213
   * ``get_attender("scaledot")`` / ``DotAttender``
                                 npf/architectures/attention.py:16-86,89-220
-``MLP(is_res=True)`` and the concatenating merge are covered too; what else the reference offers in
-those files (other activations, dropout, the other attention flavours) raises ``NotImplementedError``
-here instead of silently running somewhere else.
+``MLP(is_res=True)``, MLP dropout and the concatenating merge are covered too; what else the reference offers
+in those files (other activations, attention dropout, the other attention flavours) raises
+``NotImplementedError`` here instead of silently running somewhere else.
 
 ``forward`` takes row-major device tensors like the reference; internally every module can
 also append itself to a :class:`~npf_gwwaveform_amd.chain.Chain` (``append_to``), which is how
@@ -49,8 +49,8 @@ class MLP(nn.Module):
         super().__init__()
         activation = nn.ReLU() if activation is None else activation
         _check_relu(activation)
-        if dropout != 0:
-            raise NotImplementedError("dropout is not on the hot path (the reference's 1-D models use dropout=0)")
+        if not 0 <= dropout < 1:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         self.input_size, self.output_size, self.n_hidden_layers, self.is_res = input_size, output_size, n_hidden_layers, is_res
         self.hidden_size = hidden_size
         if is_force_hid_smaller and self.hidden_size > max(output_size, input_size):
@@ -61,7 +61,8 @@ class MLP(nn.Module):
             self.hidden_size = min(output_size, input_size)
             warnings.warn(f"hidden_size={hidden_size} smaller than output={output_size} and input={input_size}. "
                           f"Setting it to {self.hidden_size}.")
-        self.dropout = nn.Identity()
+        self.dropout_p = float(dropout)
+        self.dropout = nn.Dropout(p=dropout) if dropout > 0 else nn.Identity()  # (interface; the mask is applied in-kernel)
         self.activation = activation
         self.to_hidden = nn.Linear(input_size, self.hidden_size, bias=is_bias)
         self.linears = nn.ModuleList(
@@ -101,7 +102,23 @@ class MLP(nn.Module):
                 W = torch.nn.functional.pad(W, (0, pad))
                 ch.F = W.shape[1]
             ch.linear(W, lin.bias, relu=(j < len(ls) - 1), residual=(self.is_res and 0 < j < len(ls) - 1))
+            if j < len(ls) - 1 and self.dropout_p > 0 and self.training:
+                ch.dropout(self._sign_mask(ch, lin.out_features), self.dropout_p)  # mlp.py:98,105: after activation (+ residual)
         return ch
+
+    # tests: an iterator of row-major keep masks [n_tasks * pts, F] (or [n_tasks, pts, F]) consumed in call order instead
+    # of the device generator (the reference draws its masks from torch's CPU generator, which no GPU draw reproduces)
+    mask_source = None
+
+    def _sign_mask(self, ch: Chain, F: int) -> torch.Tensor:
+        """+1 (keep, probability 1 - p) / -1 (drop) per (task, point, unit) as a PT32 tensor."""
+        from .chain import pt_shape
+
+        if MLP.mask_source is not None:
+            keep = next(MLP.mask_source).to(ch.device).reshape(ch.n_tasks, ch.pts, F).float()
+            return FN.pack_pt(keep * 2.0 - 1.0)
+        keep = torch.rand(pt_shape(ch.n_tasks, ch.pts, F), device=ch.device) < (1.0 - self.dropout_p)
+        return torch.where(keep, 1.0, -1.0)
 
     def forward(self, x):
         lead, n_in = x.shape[:-1], x.shape[-1]

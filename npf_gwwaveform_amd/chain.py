@@ -227,6 +227,14 @@ class Program:
             return
         self._op(op=L.OP_MASK_BITS, i0=pad32(F), p0=m.data_ptr())
 
+    def scale(self, f: float):
+        self._op(op=L.OP_SCALE, f0=float(f))
+
+    def mask_sign(self, t, F):
+        """cur <- t > 0 ? cur : 0 as an op of its own (dropout: ``t`` holds +1 / -1)."""
+        p, fl = self._pt(t)
+        self._op(op=L.OP_MASK_POS, i0=pad32(F), p0=p, flags=fl)
+
     def rowdot_pt(self, t, F):
         p, fl = self._pt(t)
         self._op(op=L.OP_ROWDOT_PT, i0=pad32(F), p0=p, flags=fl)
@@ -595,6 +603,14 @@ class Chain:
         self.steps.append(_Step("add_pt", {"x": self._t(t)}, {"F": self.F, "relu": relu, "mod": modulus}))
         return self
 
+    def dropout(self, sign_mask: torch.Tensor, p: float) -> "Chain":
+        """cur <- cur * keep / (1 - p) (``nn.Dropout`` in training mode, mlp.py:81,98,105): ``sign_mask`` is a PT32 tensor
+        holding +1 where the unit is kept and -1 where it is dropped (no gradient)."""
+        if not 0.0 <= p < 1.0:
+            raise ValueError(f"dropout probability {p}")
+        self.steps.append(_Step("dropout", {"m": self._t(sign_mask)}, {"F": self.F, "p": float(p)}))
+        return self
+
     def add_taskvec(self, v: torch.Tensor, relu: bool = False, modulus: int = 0) -> "Chain":
         """cur += v[task] with v row-major [n_tasks (or modulus), pad32(F)]."""
         self.steps.append(_Step("add_taskvec", {"v": self._t(v)}, {"F": self.F, "relu": relu, "mod": modulus}))
@@ -798,6 +814,10 @@ class _ChainFn(torch.autograd.Function):
                 upstream = upstream or needs_grad[st.t["x"]]
                 if train and a["relu"] and upstream:
                     save_relu_mask(i, a["F"])
+            elif k == "dropout":
+                prog.mask_sign(T[st.t["m"]], a["F"])
+                prog.scale(1.0 / (1.0 - a["p"]))
+                backed = backed16 = None
             elif k == "add_taskvec":
                 prog.add_taskvec(T[st.t["v"]], a["F"], a["relu"], a["mod"])
                 backed = backed16 = None
@@ -992,6 +1012,9 @@ class _ChainFn(torch.autograd.Function):
                         grads[idx] = (buf, a["mod"])
                     else:
                         pending_taskvec.append((idx, buf, a["F"], a["mod"]))
+            elif k == "dropout":
+                prog.mask_sign(T[st.t["m"]], a["F"])
+                prog.scale(1.0 / (1.0 - a["p"]))
             elif k == "layernorm":
                 gi, bi = st.t["g"], st.t["b"]
                 dyx = None

@@ -60,6 +60,7 @@ class OracleConfig:
                                          # reference's concatenating merge cannot serve as a decoder: its torch.cat of a
                                          # 3-d X_trgt and a 4-d R_trgt raises, encoders.py:181)
     is_res: bool = False                 # residual hidden layers in the XY-encoder / decoder flat MLPs (mlp.py:100-104)
+    dropout: float = 0.0                 # dropout of those two MLPs (mlp.py:81,98,105); masks via ``DROPOUT_MASKS``
 
     def __post_init__(self):
         if self.kind not in MODEL_KINDS:
@@ -197,38 +198,56 @@ def _relu(v: torch.Tensor) -> torch.Tensor:
     return torch.relu(v)
 
 
-def mlp(params: Params, prefix: str, x: torch.Tensor, out_db_rounded: bool = True, is_res: bool = False) -> torch.Tensor:
-    """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU, no dropout:
-    to_hidden -> relu -> [linears.i -> relu (+ its input when ``is_res``, :103-104)]* -> out (no activation).
+# Training-mode dropout: an iterator of keep masks (0 / 1, shaped like the activation) consumed in call order.  The
+# reference draws them from torch's global CPU generator inside nn.Dropout; tests capture those draws (forward hooks in
+# tests/golden/make_golden.py) and hand them to the oracle and to the HIP path alike.
+DROPOUT_MASKS = None
+TRAINING = True
+
+
+def _dropout(h: torch.Tensor, p: float) -> torch.Tensor:
+    """``nn.Dropout(p)`` in training mode (mlp.py:81) with the mask taken from ``DROPOUT_MASKS``: torch multiplies by
+    mask / (1 - p)."""
+    if p <= 0.0 or DROPOUT_MASKS is None:
+        return h
+    keep = next(DROPOUT_MASKS).reshape(h.shape).to(h.dtype)
+    return h * keep.div(1.0 - p)
+
+
+def mlp(params: Params, prefix: str, x: torch.Tensor, out_db_rounded: bool = True, is_res: bool = False,
+        dropout: float = 0.0) -> torch.Tensor:
+    """``MLP.forward`` (npf/architectures/mlp.py:95-109) with ReLU:
+    to_hidden -> relu -> dropout -> [linears.i -> relu (+ its input when ``is_res``, :103-104) -> dropout]* -> out.
     (``out_db_rounded``: bf16 emulation only, see ``_LinearBf16``.)"""
-    h = _relu(linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"]))
+    h = _dropout(_relu(linear(x, params[f"{prefix}.to_hidden.weight"], params[f"{prefix}.to_hidden.bias"])), dropout)
     i = 0
     while f"{prefix}.linears.{i}.weight" in params:
         o = _relu(linear(h, params[f"{prefix}.linears.{i}.weight"], params[f"{prefix}.linears.{i}.bias"]))
-        h = o + h if is_res else o
+        h = _dropout(o + h if is_res else o, dropout)
         i += 1
     return linear(h, params[f"{prefix}.out.weight"], params[f"{prefix}.out.bias"], out_db_rounded)
 
 
 def merge_flat_sum(params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor, fused_addend: bool = True,
-                   is_res: bool = False) -> torch.Tensor:
+                   is_res: bool = False, dropout: float = 0.0) -> torch.Tensor:
     """``MergeFlatInputs.forward`` with ``is_sum_merge=True``
     (npf/architectures/encoders.py:175-183): flat(relu(x1 + resizer(x2))).
     (``fused_addend``: bf16 emulation only -- x1 enters the resizer's last layer as its addend inside one
     chain, whose dZ buffer is then an fp32 tensor.)"""
     x2 = mlp(params, f"{prefix}.resizer", x2, out_db_rounded=not fused_addend)
-    return mlp(params, f"{prefix}.flat_module", _relu(x1 + x2), is_res=is_res)
+    return mlp(params, f"{prefix}.flat_module", _relu(x1 + x2), is_res=is_res, dropout=dropout)
 
 
 def merge_flat(cfg: "OracleConfig", params: Params, prefix: str, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """``MergeFlatInputs.forward`` (encoders.py:175-183) in the configured flavour: the sum merge above, or
     ``flat(cat(x1, x2))`` (:180-181; x1 broadcast over the leading dims of x2 like the sum would)."""
     if cfg.is_sum_merge:
-        return merge_flat_sum(params, prefix, x1, x2, is_res=cfg.is_res)
+        return merge_flat_sum(params, prefix, x1, x2, is_res=cfg.is_res, dropout=cfg.dropout if TRAINING else 0.0)
     if MATMUL_MODE == "bf16":
         raise NotImplementedError("the bf16 emulation models the sum-merge path only")
     x1 = x1.expand(*x2.shape[:-1], x1.shape[-1])
-    return mlp(params, f"{prefix}.flat_module", torch.cat((x1, x2), dim=-1), is_res=cfg.is_res)
+    return mlp(params, f"{prefix}.flat_module", torch.cat((x1, x2), dim=-1), is_res=cfg.is_res,
+               dropout=cfg.dropout if TRAINING else 0.0)
 
 
 def scaledot_attend(keys: torch.Tensor, queries: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
@@ -385,9 +404,9 @@ def decode(cfg: OracleConfig, params: Params, Xt_enc: torch.Tensor, R_trgt: torc
         # mean-aggregation models: R_trgt is one vector per (sample, task) expanded over the targets; the HIP
         # path resizes it once per task (its own small chain) and adds the result to every target in fp32
         x2 = mlp(params, "decoder.resizer", R_trgt[..., :1, :])
-        suff = mlp(params, "decoder.flat_module", _relu(Xt_enc + x2), is_res=cfg.is_res)
+        suff = mlp(params, "decoder.flat_module", _relu(Xt_enc + x2), is_res=cfg.is_res, dropout=cfg.dropout if TRAINING else 0.0)
     else:
-        suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt, is_res=cfg.is_res)
+        suff = merge_flat_sum(params, "decoder", Xt_enc, R_trgt, is_res=cfg.is_res, dropout=cfg.dropout if TRAINING else 0.0)
     loc, raw = suff.split(cfg.y_dim, dim=-1)
     scale = p_y_scale_transform(raw)
     if not cfg.is_heteroskedastic:
@@ -415,6 +434,8 @@ def forward(
     Returns a dict with ``loc``/``scale`` [n_z,B,T,dy] and, for latent models,
     ``z_samples`` and the (loc, scale) pairs ``q_zCc`` / ``q_zCct``.
     """
+    global TRAINING
+    TRAINING = training  # (nn.Dropout is the identity in evaluation mode)
     if training:
         # base.py:241-247 / npf/utils/helpers.py:55-57
         ok = ((X_cntxt >= -1) & (X_cntxt <= 1)).all() and ((X_trgt >= -1) & (X_trgt <= 1)).all()

@@ -55,14 +55,16 @@ def _latent_dist(loc, scale):
 
 def build_reference(case: dict):
     r = case["r"]
-    sm, res = case.get("is_sum_merge", True), case.get("is_res", False)
+    sm, res, drop = case.get("is_sum_merge", True), case.get("is_res", False), case.get("dropout", 0)
     kw = dict(
         r_dim=r,
         is_heteroskedastic=case.get("is_heteroskedastic", True),
         XYEncoder=merge_flat_input(
-            partial(MLP, n_hidden_layers=case["L_xy"], is_force_hid_smaller=True, hidden_size=r, is_res=res), is_sum_merge=sm
+            partial(MLP, n_hidden_layers=case["L_xy"], is_force_hid_smaller=True, hidden_size=r, is_res=res, dropout=drop),
+            is_sum_merge=sm
         ),
-        Decoder=merge_flat_input(partial(MLP, n_hidden_layers=case["L_dec"], hidden_size=r, is_res=res), is_sum_merge=True),
+        Decoder=merge_flat_input(partial(MLP, n_hidden_layers=case["L_dec"], hidden_size=r, is_res=res, dropout=drop),
+                                 is_sum_merge=True),
     )
     if "x_transf_dim" in case:
         kw["x_transf_dim"] = case["x_transf_dim"]
@@ -110,7 +112,15 @@ def run_case(name: str, case: dict, store_params: bool, store_full_grads: bool, 
         _EpsIndependent.eps = inp["eps"]
     crit = ref_loss(case)
     crit.train()
+    # the keep masks nn.Dropout draws from torch's global generator, in call order (where its input is zero the mask
+    # cannot be read off the output and does not matter: the unit contributes nothing either way)
+    drawn = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: drawn.append((o != 0).to(torch.uint8).numpy()))
+             for m in model.modules() if isinstance(m, torch.nn.Dropout)]
+    torch.manual_seed(2014)
     out = model(inp["X_cntxt"], inp["Y_cntxt"], inp["X_trgt"], inp["Y_trgt"])
+    for h in hooks:
+        h.remove()
     p_yCc, z_samples, q_zCc, q_zCct = out
     loss = crit(out, inp["Y_trgt"])
     loss.backward()
@@ -121,6 +131,8 @@ def run_case(name: str, case: dict, store_params: bool, store_full_grads: bool, 
         "loss": loss.detach().numpy(),
         "n_params": np.array(sum(p.numel() for p in model.parameters())),
     }
+    for i_m, m_ in enumerate(drawn):
+        res[f"dropmask/{i_m}"] = m_
     if z_samples is not None:
         res["z_samples"] = z_samples.detach().numpy()
         res["q_zCc_loc"] = q_zCc.base_dist.loc.detach().numpy()

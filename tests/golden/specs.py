@@ -82,6 +82,9 @@ VARIANT_CASES = {
     "g14_lnp_cat": dict(kind="LNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=9, T=40, encoded_path="latent", n_z=3,
                         is_sum_merge=False),
     "g14_attncnp_cat": dict(kind="AttnCNP", r=64, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=20, T=45, is_sum_merge=False),
+    # dropout in the XY-encoder / decoder MLPs (mlp.py:81,98,105): the masks the reference drew are stored (dropmask/i)
+    "g14_cnp_drop": dict(kind="CNP", r=32, L_xy=2, L_dec=3, dx=1, dy=2, B=3, C=9, T=40, dropout=0.25),
+    "g14_attncnp_drop_res": dict(kind="AttnCNP", r=64, L_xy=3, L_dec=3, dx=1, dy=2, B=2, C=20, T=45, dropout=0.4, is_res=True),
     "g14_attnlnp_all": dict(kind="AttnLNP", r=64, L_xy=3, L_dec=3, dx=1, dy=2, B=2, C=20, T=45, is_q_zCct=True, n_z=2,
                             is_sum_merge=False, is_res=True, x_transf_dim=32),
 }
@@ -103,7 +106,14 @@ def cfg_of(case: dict) -> O.OracleConfig:
         encoded_path=case.get("encoded_path"), is_heteroskedastic=case.get("is_heteroskedastic", True),
         is_q_zCct=case.get("is_q_zCct", False), attention=case.get("attention", "scaledot"),
         x_transf_dim=case.get("x_transf_dim"), is_sum_merge=case.get("is_sum_merge", True), is_res=case.get("is_res", False),
+        dropout=case.get("dropout", 0.0),
     )
+
+
+def golden_dropout_masks(g: dict):
+    """The keep masks of a fixture in the order the reference drew them (empty for cases without dropout)."""
+    n = sum(1 for k in g if k.startswith("dropmask/"))
+    return [torch.from_numpy(g[f"dropmask/{i}"].astype("float32")) for i in range(n)]
 
 
 def golden_params(g: dict) -> dict:

@@ -29,12 +29,14 @@ def build_model(case: dict, device="cuda:0", params=None):
     import npf_gwwaveform_amd as A
 
     r = case["r"]
-    res = case.get("is_res", False)
+    res, drop = case.get("is_res", False), case.get("dropout", 0)
     kw = dict(
         r_dim=r, is_heteroskedastic=case.get("is_heteroskedastic", True),
         XYEncoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=case["L_xy"], is_force_hid_smaller=True,
-                                             hidden_size=r, is_res=res), is_sum_merge=case.get("is_sum_merge", True)),
-        Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=case["L_dec"], hidden_size=r, is_res=res), is_sum_merge=True),
+                                             hidden_size=r, is_res=res, dropout=drop),
+                                     is_sum_merge=case.get("is_sum_merge", True)),
+        Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=case["L_dec"], hidden_size=r, is_res=res, dropout=drop),
+                                   is_sum_merge=True),
     )
     if "x_transf_dim" in case:
         kw["x_transf_dim"] = case["x_transf_dim"]

@@ -67,9 +67,15 @@ def test_model_variants_parity(name):
     """G14: ``MLP(is_res=True)`` (mlp.py:100-104), the concatenating XY-encoder merge (encoders.py:180-181) and
     ``x_transf_dim`` != ``r_dim`` (base.py:126-131) against the reference's outputs, loss, every gradient and its
     evaluation-mode outputs -- on the parameters the reference constructed (stored in the fixture)."""
+    import npf_gwwaveform_amd as A
+
     case = specs.VARIANT_CASES[name]
     g = specs.load_golden(name)
-    model, out, loss = _run(case, params=specs.golden_params(g))
+    A.MLP.mask_source = iter(specs.golden_dropout_masks(g))  # (the masks the reference drew; none without dropout)
+    try:
+        model, out, loss = _run(case, params=specs.golden_params(g))
+    finally:
+        A.MLP.mask_source = None
     p_yCc, z_samples, q_zCc, q_zCct = out
     assert_close(p_yCc.base_dist.loc, g["loc"], what="loc")
     assert_close(p_yCc.base_dist.scale, g["scale"], what="scale")
@@ -84,6 +90,46 @@ def test_model_variants_parity(name):
     _, out_e, _ = _run(case, train=False, params=specs.golden_params(g))
     assert_close(out_e[0].base_dist.loc, g["eval_loc"], what="eval loc")
     assert_close(out_e[0].base_dist.scale, g["eval_scale"], what="eval scale")
+
+
+def test_mlp_dropout_with_device_masks():
+    """``MLP(dropout=p)`` with masks drawn on the device (no injected masks): evaluation mode is the identity, training
+    mode zeroes about p of the hidden units' contributions and rescales by 1 / (1 - p) (mean preserved), the backward
+    pass uses the same mask (a unit dropped in the forward pass gets no gradient through it)."""
+    import npf_gwwaveform_amd as A
+
+    torch.manual_seed(5)
+    p = 0.5
+    m = A.MLP(16, 8, hidden_size=64, n_hidden_layers=1, dropout=p).to(DEV)
+    ref = A.MLP(16, 8, hidden_size=64, n_hidden_layers=1).to(DEV)
+    ref.load_state_dict(m.state_dict())
+    x = torch.randn(4000, 16, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(m.eval()(x), ref.eval()(x))
+        y_ref = ref(x)
+        m.train()
+        y1, y2 = m(x), m(x)
+    assert not torch.equal(y1, y2)                                   # fresh masks per call
+    # out layer is linear in the (masked, rescaled) hidden units: E[y] = y_ref - b + b
+    assert_close(y1.mean(0), y_ref.mean(0), tol=5e-2, what="dropout preserves the mean")
+    # exact check against a mask reconstructed from the module's own hook point: one hidden layer, so
+    # y = W_out (keep * h / (1 - p)) + b for some 0/1 keep; solve for keep on a few rows via the gradient
+    x1 = x[:64].clone().requires_grad_(True)
+    torch.manual_seed(11)
+    y = m(x1)
+    y.sum().backward()
+    torch.manual_seed(11)
+    with torch.no_grad():
+        y_again = m(x1)
+    assert torch.equal(y, y_again)                                   # same generator state -> same masks
+    h = torch.relu(x1.detach() @ m.to_hidden.weight.t() + m.to_hidden.bias)
+    g_h = (m.out.weight.sum(0) / (1 - p)).expand_as(h)               # d sum(y) / d h where kept
+    # the input gradient is W_hid^T (keep * relu' * g_h): recover keep * relu' by least squares is overkill -- check the
+    # two extreme hypotheses instead: all kept would give gx_all; the actual gradient must be a masked version of it
+    gx_all = ((h > 0).float() * g_h) @ m.to_hidden.weight
+    assert not torch.allclose(x1.grad, gx_all, rtol=1e-3, atol=1e-5)
+    frac = float(x1.grad.norm() / gx_all.detach().norm())
+    assert 0.4 < frac < 1.1, frac                                    # about sqrt(1 - p) of the units' share survives
 
 
 @pytest.mark.parametrize("name", ["g1_cnp_c1", "g2_lnp_both_c1", "g3s_attncnp_r64", "g4s_attnlnp_r64", "g6_cnp_homosk",

@@ -180,8 +180,9 @@ def test_unsupported_configurations_fail_loudly():
         A.AttnCNP(1, 1, is_self_attn=True, self_attention_kwargs=dict(positional="absolute", position_dim=1))
     with pytest.raises(NotImplementedError):
         A.MLP(4, 4, activation=torch.nn.GELU())
-    with pytest.raises(NotImplementedError):
-        A.MLP(4, 4, dropout=0.1)
+    assert isinstance(A.MLP(4, 4, dropout=0.1).dropout, torch.nn.Dropout) and A.MLP(4, 4).dropout_p == 0.0
+    with pytest.raises(ValueError):
+        A.MLP(4, 4, dropout=1.0)
     cat = A.merge_flat_input(A.MLP, is_sum_merge=False)(8, 2, 8)   # concatenating merge: one MLP over x1 | x2
     assert not hasattr(cat, "resizer") and cat.flat_module.to_hidden.in_features == 10
     res = A.MLP(8, 8, hidden_size=8, n_hidden_layers=3, is_res=True)
