@@ -336,6 +336,11 @@ def profile_launches(step, n_prof: int, rank: int, sync, CH):
         kernels[name] = {"launches_per_step": n / n_prof, "avg_launch_ms": sec / n * 1e3,
                          "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
                          "algorithmic_hbm_gb_per_launch": nb / n * 1e-9, "algorithmic_hbm_gbps": nb / sec * 1e-9}
+    if "wgrad_kernel" in kernels and CH.COMPUTE_DTYPE != "bf16" and CH.WGRAD_X6:
+        # (the rate can exceed the fp32 MFMA peak: these launches run on the bf16 matrix pipe)
+        kernels["wgrad_kernel"]["note"] = ("wgrad_x6_kernel: fp32 operands split exactly into three bf16 terms, six "
+                                           "v_mfma_f32_16x16x32_bf16 per product group, fp32 accumulation -- an fp32 result on "
+                                           "the bf16 pipe (DESIGN.md 3.2); NPF_NO_WGRAD_X6=1 = the fp32-MFMA kernel")
     return agg, kernels
 
 
@@ -483,7 +488,9 @@ def main_train(args, rank, world, dev, sync, rehearsal):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
+            "dtype": ("f32" if os.environ.get("NPF_NO_WGRAD_X6", "0") == "1" else
+                      "f32 (chain kernels: v_mfma_f32_16x16x4_f32; weight gradients: fp32 operands as three exact bf16 terms on the bf16 matrix pipe, f32 accumulation)")
+            if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
                 "workload": f"{'BASELINE config ' + str(args.config_number) if args.attention == 'scaledot' else 'example (not a BASELINE config)'}: {model_name} {args.attention}, r={args.r}, {args.layers}-layer "
