@@ -442,7 +442,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void wgrad_kernel(const WgradJobs J,
 // two sets) needed two barriers and a vector-only phase per tile: 1.55 ms; splitting at the read with the compiler's
 // lowering of __builtin_convertvector (16 instructions per pair) 1.58, hand-written (11) 1.47, interleaved with the
 // MFMAs and with the DMA issue spread 1.38.  With zeros in LDS (no DMA) the same code runs 1.05: the rest is the
-// clock the chip holds with real operands on the bf16 pipe.
+// clock the chip holds with real operands on the bf16 pipe.  Narrow jobs (one column block with data) still run all eight
+// steps of a wave: a pipeline per column block (four steps each, no wasted MFMAs: 256 x 4 over 262 144 points 0.186 ->
+// 0.150 ms) costs the square jobs a pipeline fill per tile (1.38 -> 1.46 ms), and a shortened second copy of the
+// eight-step loop spilled 60 - 100 registers however it was written; not kept.
 constexpr int kXThreads = 512;
 constexpr int kXWaves = kXThreads / 64;
 
