@@ -41,6 +41,7 @@ FUSE_STORES = os.environ.get("NPF_NO_FUSED_STORE", "0") != "1"  # bf16 mode: STO
 # terms, six cross products accumulated in fp32 (NPF_WGRAD_F32X6: the result agrees with the v_mfma_f32_16x16x4_f32
 # kernel to fp32 summation-order noise, at 6/16 of its matrix-pipe time).  NPF_NO_WGRAD_X6=1: the native fp32 kernel.
 WGRAD_X6 = os.environ.get("NPF_NO_WGRAD_X6", "0") != "1"
+X6_NARROW_NATIVE = os.environ.get("NPF_X6_ALL", "0") != "1"  # narrow jobs of an fp32 launch keep the fp32-MFMA kernel
 
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
@@ -441,8 +442,23 @@ def _block_jobs(jobs: Sequence[dict]) -> List[dict]:
 
 
 def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
-    lib = L.load()
     jobs = _block_jobs(jobs)
+    x6 = WGRAD_X6 and COMPUTE_DTYPE != "bf16"
+    if x6 and X6_NARROW_NATIVE:
+        # narrow jobs (first / last layers: 256 x 4, 4 x 256, 32 x 2 ...) are bandwidth-bound and leave most of a split-kernel
+        # workgroup idle (a 256 x 4 job over 262 144 points: 0.19 ms there, 0.11 ms on the fp32 kernel): their own launch
+        narrow = [jb for jb in jobs if min(jb["N"], jb["K"]) <= 32]
+        wide = [jb for jb in jobs if min(jb["N"], jb["K"]) > 32]
+        if narrow and wide:
+            _launch_wgrad(wide, n_tasks, pts, device, True)
+            _launch_wgrad(narrow, n_tasks, pts, device, False)
+            return
+        x6 = bool(wide)
+    _launch_wgrad(jobs, n_tasks, pts, device, x6)
+
+
+def _launch_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device, x6: bool) -> None:
+    lib = L.load()
     for i0 in range(0, len(jobs), L.NPF_MAX_WGRAD_JOBS):
         chunk = jobs[i0:i0 + L.NPF_MAX_WGRAD_JOBS]
         arr = (L.NpfWgradJob * len(chunk))()
@@ -461,7 +477,7 @@ def _run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
             # bit 1: bf16 products (bf16 compute mode: every weight / key / value gradient of the step)
             arr[j].accumulate = (int(jb.get("accumulate", False)) | (2 if COMPUTE_DTYPE == "bf16" else 0)
                                  | (4 if z16 else 0) | (8 if a16 else 0)
-                                 | (L.WGRAD_F32X6 if WGRAD_X6 and COMPUTE_DTYPE != "bf16" else 0))
+                                 | (L.WGRAD_F32X6 if x6 else 0))
         nbytes = lib.npf_wgrad_partials_bytes(arr, len(chunk), n_tasks, tiles_of(pts))
         if nbytes < 0:
             raise RuntimeError("npf_wgrad_partials_bytes: invalid wgrad jobs")

@@ -34,6 +34,13 @@ def _random_case(rng: random.Random) -> dict:
         case["encoded_path"] = rng.choice(["latent", "both"])
     if kind in ("AttnCNP", "AttnLNP") and r % 32 == 0 and rng.random() < 0.3:
         case["attention"] = rng.choice(["multihead", "transformer"])
+    # the reference's other MLP / merge options
+    if rng.random() < 0.25:
+        case["is_res"] = True
+    if case.get("attention", "scaledot") == "scaledot" and rng.random() < 0.25:
+        case["x_transf_dim"] = rng.choice([8, 20, 32, 64, 100, 128, 256])
+    if rng.random() < 0.2:
+        case["is_sum_merge"] = False
     return case
 
 
@@ -43,7 +50,8 @@ def test_random_shapes_match_oracle():
     failures, ties = [], 0
     for i in range(N_CASES):
         case = _random_case(rng)
-        if DTYPE == "bf16" and (case.get("attention", "scaledot") != "scaledot" or case["C"] > 256):
+        if DTYPE == "bf16" and (case.get("attention", "scaledot") != "scaledot" or case["C"] > 256
+                                or not case.get("is_sum_merge", True)):
             continue  # (the bf16 emulation models the fused scaled-dot family; the rest keeps fp32 attention launches)
         try:
             params = specs.make_params(case, seed=100 + i)
