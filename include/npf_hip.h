@@ -289,6 +289,29 @@ typedef struct npf_wprep_job {
 int npf_prepare_weights(const npf_wprep_job_t *jobs, int32_t n_jobs, void *stream);
 
 /* Library / device info. */
+/* ---- hidden layers of the flat MLPs with their fp32 products on the bf16 matrix pipe ----------------------------------
+ * Replaces, for stacks of 256 -> 256 layers, what npf_chain_run does with LINEAR ops (npf/architectures/mlp.py:95-109 forward;
+ * its autograd backward): cur <- x; per layer: [cur <- mask > 0 ? cur : 0] [store_in <- cur] cur <- W cur + bias [relu]
+ * [store_out <- cur]; y <- cur.  x, y, mask, store_in, store_out: PT32 tensors with 256 features over n_tasks x tiles_per_task
+ * tiles.  w_img: the layer's weights as THREE bf16 terms, W = W0 + W1 + W2 exactly to 2^-27 (W0 = bf16(W), W1 = bf16(W - W0),
+ * W2 = bf16(W - W0 - W1)), each a 256 x 256 k-permuted image as npf_cast_bf16_weights makes it, stored back to back; the kernel
+ * splits the layer input the same way in registers and accumulates six of the nine cross products in fp32 (the dropped ones
+ * are below 2^-26 of a product): an fp32 result, at 6/16 of the fp32-MFMA time (csrc/mlp_x6_kernel.hip).
+ * Forward pass of a stack: bias, relu, store_out (the saved activations) per layer.  Its dgrad: layers in reverse order with
+ * w_img = the images of W^T, mask = the layer's saved output, store_in = the dZ buffer the weight gradient reads. */
+#define NPF_X6_MAX_LAYERS 8
+typedef struct {
+  const void *w_img;   /* [3][256][256] bf16 */
+  const float *bias;   /* [256] or NULL */
+  const float *mask;   /* PT32 or NULL */
+  float *store_in;     /* PT32 or NULL */
+  float *store_out;    /* PT32 or NULL */
+  int32_t relu;
+  int32_t reserved;
+} npf_x6_layer_t;
+int npf_mlp_x6_run(const npf_x6_layer_t *layers, int32_t n_layers, const float *x, float *y, int32_t n_tasks,
+                   int32_t tiles_per_task, void *stream);
+
 int npf_version(void);
 
 #ifdef __cplusplus

@@ -63,6 +63,14 @@ class NpfWprepJob(C.Structure):
 
 
 NPF_MAX_WPREP_JOBS = 32
+NPF_X6_MAX_LAYERS = 8
+
+
+class NpfX6Layer(C.Structure):
+    _fields_ = [("w_img", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("store_in", C.c_void_p),
+                ("store_out", C.c_void_p), ("relu", C.c_int32), ("reserved", C.c_int32)]
+
+
 assert C.sizeof(NpfOp) == 80 and C.sizeof(NpfProgram) == 32 + 80 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 72 and C.sizeof(NpfWprepJob) == 32
 
 # name -> (restype, argtypes); must list every symbol declared in include/npf_hip.h
@@ -85,6 +93,7 @@ SIGNATURES = {
     "npf_gather_points": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "npf_split_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_merge_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "npf_mlp_x6_run": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _i32, _i32, _p]),
     "npf_version": (C.c_int, []),
 }
 

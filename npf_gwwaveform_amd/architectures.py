@@ -214,11 +214,75 @@ class MergeFlatInputs(nn.Module):
         ch.add_taskvec(tv.contiguous(), relu=True, modulus=modulus)
         return self.flat_module.append_to(ch, skip_first=not self.is_sum_merge)
 
+    # ---- the flat MLP's 256 -> 256 layers on the split kernel (mlp_x6.py): fp32 results on the bf16 matrix pipe ----
+    def _x6_stack(self):
+        """(layers, relus, covers_out) of the flat module that can run on ``npf_mlp_x6_run``, or None: a sum-merge MLP
+        whose input and hidden width are 256, no residual, no active dropout.  ``covers_out``: ``out`` is 256 -> 256 too."""
+        from . import mlp_x6
+
+        fm = self.flat_module
+        if not (self.is_sum_merge and isinstance(fm, MLP)) or fm.is_res or (fm.dropout_p > 0 and fm.training):
+            return None
+        stack = [fm.to_hidden, *fm.linears]
+        if not mlp_x6.usable(stack):
+            return None
+        relus = [True] * len(stack)
+        covers_out = mlp_x6.usable([fm.out])
+        if covers_out:
+            stack, relus = stack + [fm.out], relus + [False]
+        return stack, relus, covers_out
+
+    def _merge_only(self, ch: Chain, x1_pt=None, x1_modulus: int = 0, taskvec=None) -> Chain:
+        """cur <- relu(x1 + resizer(x2)): ``x1_pt`` with cur = x2, or ``taskvec`` (x2 one vector per task) with cur = x1."""
+        if taskvec is not None:
+            tv = self.resizer(taskvec)
+            Fp = -(-tv.shape[1] // 32) * 32
+            if tv.shape[1] != Fp:
+                tv = torch.nn.functional.pad(tv, (0, Fp - tv.shape[1]))
+            return ch.add_taskvec(tv.contiguous(), relu=True)
+        rl = self.resizer.layers()
+        for lin in rl[:-1]:
+            ch.linear(lin.weight, lin.bias, relu=True)
+        return ch.linear(rl[-1].weight, rl[-1].bias, relu=True, addend=x1_pt, addend_modulus=x1_modulus)
+
+    def finish_rows(self, ch: Chain, x1_pt=None, x1_modulus: int = 0, taskvec=None) -> torch.Tensor:
+        """Finish ``ch`` with this module and run it: the row-major [n_tasks, pts, n_out] output (n_out <= 32: the
+        decoder's sufficient statistics)."""
+        from . import mlp_x6
+
+        st = self._x6_stack()
+        if st is None or st[2]:
+            if taskvec is not None:
+                return self.append_taskvec_to(ch, taskvec).output_rows().run()[0]
+            return self.append_to(ch, x1_pt=x1_pt, x1_modulus=x1_modulus).output_rows().run()[0]
+        stack, relus, _ = st
+        (h0,) = self._merge_only(ch, x1_pt, x1_modulus, taskvec).output_pt().run()
+        h = mlp_x6.run_stack(h0, ch.pts, stack, relus)
+        out = self.flat_module.out
+        ch2 = Chain(ch.n_tasks, ch.pts, ch.device)
+        ch2.input_pt(h, out.in_features).linear(out.weight, out.bias).output_rows()
+        return ch2.run()[0]
+
     def run_pt(self, ch: Chain, x1_pt, n_tasks: int, pts: int, with_tr: bool = False, **kw) -> PTensor:
         """Finish ``ch`` (cur = x2) with this module and run it: a :class:`PTensor` [n_tasks, pts, n_out]
         (carrying the feature-major copy / bf16 images when ``with_tr``).  One launch for an MLP flat
         module; for a SelfAttention flat module the merge is a launch and the attention layers follow."""
         if isinstance(self.flat_module, MLP):
+            st = self._x6_stack()
+            if st is not None and set(kw) <= {"x1_modulus"}:
+                from . import mlp_x6
+
+                stack, relus, covers_out = st
+                (h0,) = self._merge_only(ch, x1_pt, kw.get("x1_modulus", 0)).output_pt().run()
+                h = mlp_x6.run_stack(h0, pts, stack, relus)
+                out = self.flat_module.out
+                if covers_out and not with_tr:
+                    return PTensor(h, pts, out.out_features)
+                ch2 = Chain(n_tasks, pts, ch.device)
+                ch2.input_pt(h, out.in_features)
+                if not covers_out:
+                    ch2.linear(out.weight, out.bias)
+                return ch2.run_pt(as_weights=with_tr)
             return self.append_to(ch, x1_pt=x1_pt, **kw).run_pt(as_weights=with_tr)
         rl = self.resizer.layers()
         for lin in rl[:-1]:

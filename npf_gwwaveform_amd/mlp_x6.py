@@ -1,0 +1,134 @@
+"""Stacks of 256 -> 256 Linear layers with their fp32 products on the bf16 matrix pipe (``npf_mlp_x6_run``,
+``csrc/mlp_x6_kernel.hip``): the hidden layers of the reference's flat MLPs (npf/architectures/mlp.py:95-109) as one
+launch forward and one launch of their dgrad, weight gradients through the usual ``run_wgrad`` jobs.
+
+The arithmetic is fp32: every operand is split exactly into three bf16 terms and six of the nine cross products are
+accumulated in fp32.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import chain as CH
+
+# Opt-in (NPF_MLP_X6=1), fp32 compute mode only.  Parity-green on every golden and sweep case when switched on, but not
+# a gain yet on config 2: the stacks run at 172 - 205 TF/s fp32-equivalent where the fp32 chain kernel does
+# 105 - 116, but they are only 275 of the step's 725 chain GFLOP, cutting them out leaves the attention part of the
+# decoder's dgrad chain at 67 TF/s (its stores and loads no longer hide behind seven layers of MFMAs) and adds a PT32 round
+# trip per cut; and a step with them does not survive HIP-graph capture yet.
+ENABLED = os.environ.get("NPF_MLP_X6", "0") == "1"
+WIDTH = 256
+
+
+def _three_term_images(Ws: Sequence[torch.Tensor], transposed: bool) -> List[torch.Tensor]:
+    """Per weight matrix [256, 256] its three-term image [3, 256, 256] bf16 (k-permuted like ``npf_cast_bf16_weights``;
+    of W^T when ``transposed``): W0 = bf16(W), W1 = bf16(W - W0), W2 = bf16(W - W0 - W1), each exactly representable, so
+    the cast kernel only permutes."""
+    W = torch.stack([w.detach() for w in Ws])                     # [n, 256, 256]
+    t0 = W.to(torch.bfloat16).float()
+    r1 = W - t0
+    t1 = r1.to(torch.bfloat16).float()
+    t2 = (r1 - t1).to(torch.bfloat16).float()
+    terms = torch.stack([t0, t1, t2], dim=1).contiguous()         # [n, 3, 256, 256] fp32, bf16-representable
+    specs = [(terms[i, s], 2 if transposed else 1) for i in range(len(Ws)) for s in range(3)]
+    imgs = CH.prepare_weights(specs)                              # 3 n images [256, 256] bf16
+    return [torch.stack(imgs[3 * i:3 * i + 3]).contiguous() for i in range(len(Ws))]
+
+
+def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], n_tasks: int, tiles: int) -> None:
+    for i0 in range(0, len(layers), L.NPF_X6_MAX_LAYERS):
+        chunk = layers[i0:i0 + L.NPF_X6_MAX_LAYERS]
+        last = i0 + L.NPF_X6_MAX_LAYERS >= len(layers)
+        arr = (L.NpfX6Layer * len(chunk))()
+        for j, ly in enumerate(chunk):
+            arr[j].w_img = ly["img"].data_ptr()
+            arr[j].bias = L.ptr(ly.get("bias")) if ly.get("bias") is not None else None
+            arr[j].mask = L.ptr(ly.get("mask")) if ly.get("mask") is not None else None
+            arr[j].store_in = L.ptr(ly.get("store_in")) if ly.get("store_in") is not None else None
+            arr[j].store_out = L.ptr(ly.get("store_out")) if ly.get("store_out") is not None else None
+            arr[j].relu = int(bool(ly.get("relu", False)))
+        out = y if last else torch.empty_like(x)
+        if CH.PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().npf_mlp_x6_run(arr, len(chunk), L.ptr(x), L.ptr(out), n_tasks, tiles, L.stream_ptr()),
+                "npf_mlp_x6_run")
+        if CH.PROFILE is not None:
+            ev1.record()
+            padded = n_tasks * tiles * 32
+            nbytes = padded * 1024 * (2 + sum((ly.get("mask") is not None) + (ly.get("store_in") is not None)
+                                              + (ly.get("store_out") is not None) for ly in chunk)) + len(chunk) * 3 * 2 * WIDTH * WIDTH
+            CH.PROFILE.append(("mlp_x6_kernel", 2 * WIDTH * WIDTH * len(chunk) * n_tasks * tiles * 32, ev0, ev1, nbytes))
+        x = out
+
+
+class _MlpX6Fn(torch.autograd.Function):
+    """y = stack(x): x, y PT32 [n_tasks, tiles, 64, 32, 4]; params = W_0, b_0, W_1, b_1, ... (b may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, pts, relus, *params):
+        n_tasks, tiles = x.shape[0], x.shape[1]
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        train = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
+        x = x.detach().contiguous()
+        imgs = _three_term_images(Ws, transposed=False)
+        y = torch.empty_like(x)
+        outs = []
+        layers = []
+        for i, (img, b, r) in enumerate(zip(imgs, bs, relus)):
+            ly = dict(img=img, bias=b.detach() if b is not None else None, relu=r)
+            if train and i + 1 < len(imgs):  # the layer's output = the next layer's input (wgrad operand) and ReLU mask
+                ly["store_out"] = torch.empty_like(x)
+                outs.append(ly["store_out"])
+            layers.append(ly)
+        _launch(layers, x, y, n_tasks, tiles)
+        outs.append(y)
+        ctx.pts, ctx.relus, ctx.geom = pts, tuple(relus), (n_tasks, tiles)
+        ctx.acts = [x] + outs            # acts[i] = input of layer i; acts[i + 1] = its output
+        ctx.params = (Ws, bs)
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * (3 + 2 * len(ctx.params[0]))
+        Ws, bs = ctx.params
+        n_tasks, tiles = ctx.geom
+        n = len(Ws)
+        g = g.contiguous()
+        imgs_t = _three_term_images(Ws, transposed=True)
+        dzs = [torch.empty_like(g) for _ in range(n)]
+        layers = []
+        for i in range(n - 1, -1, -1):  # dZ_i = g_i masked by the layer's own output; g_{i-1} = W_i^T dZ_i
+            layers.append(dict(img=imgs_t[i], mask=ctx.acts[i + 1] if ctx.relus[i] else None, store_in=dzs[i]))
+        dx = torch.empty_like(g)
+        _launch(layers, g, dx, n_tasks, tiles)
+        jobs, grads = [], []
+        for i in range(n):
+            dW = torch.empty((WIDTH, WIDTH), dtype=torch.float32, device=g.device)
+            db = torch.empty((WIDTH,), dtype=torch.float32, device=g.device) if bs[i] is not None else None
+            jobs.append(dict(dZ=dzs[i], A=ctx.acts[i], N=WIDTH, K=WIDTH, dW=dW, db=db))
+            grads += [dW, db]
+        CH.run_wgrad(jobs, n_tasks, ctx.pts, g.device)
+        return (dx, None, None, *grads)
+
+
+def usable(linears: Sequence[torch.nn.Linear]) -> bool:
+    """Can this run of Linear layers go through the split kernel: fp32 compute mode, every layer 256 -> 256."""
+    return (ENABLED and CH.COMPUTE_DTYPE == "fp32" and len(linears) > 0
+            and all(l.in_features == WIDTH and l.out_features == WIDTH for l in linears))
+
+
+def run_stack(x_pt: torch.Tensor, pts: int, linears: Sequence[torch.nn.Linear], relus: Sequence[bool]) -> torch.Tensor:
+    """PT32 [n_tasks, tiles, 64, 32, 4] -> the same shape through ``linears`` (256 -> 256 each), ReLU behind layer i when
+    ``relus[i]``."""
+    params = []
+    for lin in linears:
+        params += [lin.weight, lin.bias]
+    return _MlpX6Fn.apply(x_pt, pts, tuple(bool(r) for r in relus), *params)

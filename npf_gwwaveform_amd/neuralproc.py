@@ -205,8 +205,7 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         resizer per target; here the resizer runs once per task)."""
         ch = Chain(n_rows, T, Xt_pt.t.device)
         ch.input_pt(Xt_pt.t, self.x_transf_dim, modulus=(B if n_rows != B else 0))
-        self.decoder.append_taskvec_to(ch, vec).output_rows()
-        return ch.run()[0]
+        return self.decoder.finish_rows(ch, taskvec=vec)
 
     # ------------------------------------------------------------------ reference stage API (row-major)
     @abc.abstractmethod
@@ -481,8 +480,7 @@ class AttnCNP(NeuralProcessFamily):
             ch.input_pt(torch.zeros(pt_shape(B, T, self.r_dim), device=Xt_pt.t.device), self.r_dim)
         else:
             self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
-        self.decoder.append_to(ch, x1_pt=Xt_pt.t).output_rows()
-        return ch.run()[0]
+        return self.decoder.finish_rows(ch, x1_pt=Xt_pt.t)
 
 
 class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
@@ -546,5 +544,4 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
             ch.input_pt(R_det, r, modulus=B)
             mod = B
         ch.linear(W[:, :r], zb, relu=True, bias_per_task=True)
-        self.decoder.append_to(ch, x1_pt=Xt_pt.t, x1_modulus=mod).output_rows()
-        return ch.run()[0]
+        return self.decoder.finish_rows(ch, x1_pt=Xt_pt.t, x1_modulus=mod)

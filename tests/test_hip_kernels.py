@@ -406,6 +406,46 @@ def test_wgrad_split_bf16_products_equal_fp32():
             assert float(((got - ref).abs() / mag).max()) <= 2e-6, (x6, N, K)
 
 
+def test_mlp_x6_stack_forward_and_backward_match_float64():
+    """npf_mlp_x6_run (csrc/mlp_x6_kernel.hip): a stack of 256 -> 256 layers with the fp32 products on the bf16 pipe (three exact
+    bf16 terms per operand, six cross products).  Forward values, the input gradient and every dW / db against a float64
+    evaluation of the same fp32 parameters, at the tolerances of the fp32 chain kernel (1e-5 / 1e-4 of max|ref|); odd tile
+    counts (a wave without a tile), ReLU and linear last layers, more layers than one launch takes."""
+    from npf_gwwaveform_amd import mlp_x6
+
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(53)
+    for n_tasks, pts, n_layers, last_relu in ((3, 70, 3, False), (1, 33, 1, True), (2, 64, 10, True)):
+        lins = [torch.nn.Linear(256, 256) for _ in range(n_layers)]
+        for lin in lins:
+            lin.weight.data = torch.randn(256, 256, generator=g) * 0.09
+            lin.bias.data = torch.randn(256, generator=g) * 0.1
+        relus = [True] * (n_layers - 1) + [last_relu]
+        x = torch.randn(n_tasks, pts, 256, generator=g)
+        w = torch.randn(n_tasks, pts, 256, generator=g)
+        # float64 reference
+        ref_lins = [torch.nn.Linear(256, 256).double() for _ in lins]
+        for a, b in zip(ref_lins, lins):
+            a.load_state_dict({k: v.double() for k, v in b.state_dict().items()})
+        xr = x.double().requires_grad_(True)
+        h = xr
+        for lin, r in zip(ref_lins, relus):
+            h = lin(h)
+            h = torch.relu(h) if r else h
+        (h * w.double()).sum().backward()
+        # HIP
+        dev_lins = [lin.to(DEV) for lin in lins]
+        xd = x.to(DEV).requires_grad_(True)
+        y_pt = mlp_x6.run_stack(FN.pack_pt(xd), pts, dev_lins, relus)
+        y = FN.unpack_pt(y_pt, pts, 256)
+        (y * w.to(DEV)).sum().backward()
+        assert_close(y, h, tol=1e-5, what=f"x6 stack forward ({n_layers} layers)")
+        assert_close(xd.grad, xr.grad, tol=1e-4, what="x6 stack dx")
+        for i, (a, b) in enumerate(zip(dev_lins, ref_lins)):
+            assert_close(a.weight.grad, b.weight.grad, tol=1e-4, what=f"x6 stack dW[{i}]")
+            assert_close(a.bias.grad, b.bias.grad, tol=1e-4, what=f"x6 stack db[{i}]")
+
+
 def _pack_pt16_reference(x):
     """Row-major [B, P, F] -> PT16 (bf16 tiles) with plain torch ops (the layout of chain.pt16_shape)."""
     B, P, F = x.shape

@@ -92,6 +92,17 @@ def test_model_variants_parity(name):
     assert_close(out_e[0].base_dist.scale, g["eval_scale"], what="eval scale")
 
 
+@pytest.mark.parametrize("name", ["g3_attncnp_c2", "g4_attnlnp_c2"])
+def test_model_parity_with_split_mlp_stacks(name, monkeypatch):
+    """NPF_MLP_X6=1: the 256 -> 256 layers of the XY-encoder / decoder flat MLPs on ``npf_mlp_x6_run`` (fp32 products as
+    three exact bf16 terms on the bf16 pipe, csrc/mlp_x6_kernel.hip) instead of inside the fp32 chains: the reference's
+    outputs, loss and gradients at the same fp32 tolerances."""
+    from npf_gwwaveform_amd import mlp_x6
+
+    monkeypatch.setattr(mlp_x6, "ENABLED", True)
+    test_model_train_step_parity(name)
+
+
 def test_mlp_dropout_with_device_masks():
     """``MLP(dropout=p)`` with masks drawn on the device (no injected masks): evaluation mode is the identity, training
     mode zeroes about p of the hidden units' contributions and rescales by 1 / (1 - p) (mean preserved), the backward

@@ -66,6 +66,8 @@ def test_two_rank_trainer_equals_global_batch_step(name, tmp_path):
         assert abs(mean_loss - ref_losses[s]) <= 2e-6 * abs(ref_losses[s]), (s, mean_loss, ref_losses[s])
         g, want = res[0]["grads"][s].double(), ref_grads[s].double()
         assert (g - want).abs().max() <= 1e-6 * want.abs().max(), (s, float((g - want).abs().max()), float(want.abs().max()))
-    # post-Adam weights after the steps: 1e-6 (absolute; lr = 1e-3, weights O(0.1))
+    # post-Adam weights after the steps: 1e-5 absolute = 1 % of lr = 1e-3 (weights O(0.1)).  Adam divides by sqrt(v): where
+    # a gradient entry is ~1e-3 of the tensor's largest, the 1e-6-of-max summation-order difference above is 1e-3 of the
+    # entry itself and moves that weight's step by 1e-3 lr; the largest such entry seen is 4e-6
     d = (res[0]["weights"].double() - ref_w.double()).abs()
-    assert d.max() <= 1e-6, float(d.max())
+    assert d.max() <= 1e-5, float(d.max())
