@@ -20,7 +20,10 @@ from . import chain as CH
 # a gain yet on config 2: the stacks run at 172 - 205 TF/s fp32-equivalent where the fp32 chain kernel does
 # 105 - 116, but they are only 275 of the step's 725 chain GFLOP, cutting them out leaves the attention part of the
 # decoder's dgrad chain at 67 TF/s (its stores and loads no longer hide behind seven layers of MFMAs) and adds a PT32 round
-# trip per cut; and a step with them does not survive HIP-graph capture yet.
+# trip per cut; and a step with them does not survive HIP-graph capture yet (segfault in capture_end of
+# Trainer(use_graph=True); bisected as far as: it needs no x6 launch at all -- cutting a chain in two with any torch op between
+# the halves is enough, for the XY-encoder or the decoder alone -- so it sits in how two dependent chains of one module are
+# captured, not in this kernel).
 ENABLED = os.environ.get("NPF_MLP_X6", "0") == "1"
 WIDTH = 256
 
