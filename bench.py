@@ -336,6 +336,11 @@ def profile_launches(step, n_prof: int, rank: int, sync, CH):
         kernels[name] = {"launches_per_step": n / n_prof, "avg_launch_ms": sec / n * 1e3,
                          "algorithmic_gflop_per_launch": fl / n * 1e-9, "achieved_tflops": fl / sec * 1e-12,
                          "algorithmic_hbm_gb_per_launch": nb / n * 1e-9, "algorithmic_hbm_gbps": nb / sec * 1e-9}
+    if "mlp_x6_kernel" in kernels:
+        kernels["mlp_x6_kernel"]["note"] = ("npf_mlp_x6_run: the 256 -> 256 layers of the flat MLPs (decoder resizer + merge + hidden, "
+                                            "XY-encoder flat module), fp32 operands as three exact bf16 terms, six bf16 MFMAs per "
+                                            "product group -- fp32 results on the bf16 pipe (DESIGN.md 3.2 / 3.7); NPF_NO_MLP_X6=1 "
+                                            "keeps them in the fp32 chains")
     if "wgrad_kernel" in kernels and CH.COMPUTE_DTYPE != "bf16" and CH.WGRAD_X6:
         # (the rate can exceed the fp32 MFMA peak: these launches run on the bf16 matrix pipe)
         kernels["wgrad_kernel"]["note"] = ("wgrad_x6_kernel: fp32 operands split exactly into three bf16 terms, six "
@@ -344,7 +349,11 @@ def profile_launches(step, n_prof: int, rank: int, sync, CH):
     return agg, kernels
 
 
-def roofline_of(agg, dtype: str, tag: str, preset: bool):
+# fp32 kernels that multiply on the bf16 matrix pipe (three exact bf16 terms per operand): priced against bf16 peak / 6
+SPLIT_KERNELS = set()
+
+
+def roofline_of(agg, dtype: str, tag: str, preset: bool, n_steps_prof: int = 1):
     """The dominant kernel (most device time) against its roofline.  fp32 launches are bound by the fp32
     MFMA rate.  bf16 launches have 1/16 of those MFMA cycles and are priced against both rooflines; the line
     carries the larger fraction (the binding one)."""
@@ -358,9 +367,21 @@ def roofline_of(agg, dtype: str, tag: str, preset: bool):
             roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": f_m}
         roof["frac_mfma_bf16"], roof["frac_hbm"] = f_m, f_h
         roof["achieved_tflops_algorithmic"], roof["achieved_gbps_algorithmic"] = tf, gbps
+    elif name in SPLIT_KERNELS:
+        # fp32 results from six bf16 MFMAs per product group: the pipe's dense bf16 rate / 6 is this kernel's roofline
+        roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS / 6.0, "unit": "TFLOP/s",
+                "frac": tf / (PEAK_BF16_TFLOPS / 6.0), "achieved_gbps_algorithmic": gbps,
+                "peak_is": "dense bf16 MFMA rate / 6 (fp32 operands as three exact bf16 terms, six cross products; DESIGN.md 3.2)"}
     else:
         roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / PEAK_F32_TFLOPS, "achieved_gbps_algorithmic": gbps}
+    # every kernel of the step against its own roofline (the block above is the one with the most device time)
+    roof["by_kernel"] = {
+        k: {"ms_per_step": round(v[2] / max(1, n_steps_prof) * 1e3, 3),
+            "frac": round((v[1] / v[2] * 1e-12) / ((PEAK_BF16_TFLOPS / 6.0) if (k in SPLIT_KERNELS and dtype != "bf16") else
+                                                   (PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS)), 3),
+            "of": ("bf16 MFMA / 6" if (k in SPLIT_KERNELS and dtype != "bf16") else ("bf16 MFMA" if dtype == "bf16" else "fp32 MFMA"))}
+        for k, v in agg.items()}
     roof["traffic"] = None
     # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     # rocprofv3 --pmc passes of this same command), condensed by tools/summarize_profiles.py into
@@ -410,7 +431,7 @@ def main_decode(args, rank, world, dev, sync):
     if not args.no_roofline:
         agg, kernels = profile_launches(step, 2, rank, sync, CH)
         if rank == 0:
-            roofline = roofline_of(agg, "fp32", "c5", args.preset)
+            roofline = roofline_of(agg, "fp32", "c5", args.preset, 2)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_decode(r, L, T)
@@ -467,7 +488,11 @@ def main_train(args, rank, world, dev, sync, rehearsal):
         agg, kernels = profile_launches(lambda i: trainer.step(batches[i % len(batches)], eager=True), 3, rank, sync, CH)
         if rank == 0:
             tag = args.config if not (args.config == "c4" and args.dtype == "bf16") else "c4bf16"
-            roofline = roofline_of(agg, args.dtype, tag, args.preset and args.model == "attncnp")
+            if args.dtype != "bf16":
+                SPLIT_KERNELS.add("mlp_x6_kernel")
+                if CH.WGRAD_X6:
+                    SPLIT_KERNELS.add("wgrad_kernel")
+            roofline = roofline_of(agg, args.dtype, tag, args.preset and args.model == "attncnp", 3)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -488,8 +513,8 @@ def main_train(args, rank, world, dev, sync, rehearsal):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32" if os.environ.get("NPF_NO_WGRAD_X6", "0") == "1" else
-                      "f32 (chain kernels: v_mfma_f32_16x16x4_f32; weight gradients: fp32 operands as three exact bf16 terms on the bf16 matrix pipe, f32 accumulation)")
+            "dtype": ("f32" if os.environ.get("NPF_NO_WGRAD_X6", "0") == "1" and os.environ.get("NPF_NO_MLP_X6", "0") == "1" else
+                      "f32 (attention / first / last layers: v_mfma_f32_16x16x4_f32; 256-wide MLP layers and weight gradients: fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation)")
             if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {

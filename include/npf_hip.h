@@ -291,7 +291,7 @@ int npf_prepare_weights(const npf_wprep_job_t *jobs, int32_t n_jobs, void *strea
 /* Library / device info. */
 /* ---- hidden layers of the flat MLPs with their fp32 products on the bf16 matrix pipe ----------------------------------
  * Replaces, for stacks of 256 -> 256 layers, what npf_chain_run does with LINEAR ops (npf/architectures/mlp.py:95-109 forward;
- * its autograd backward): cur <- x; per layer: [cur <- mask > 0 ? cur : 0] [store_in <- cur] cur <- W cur + bias [relu]
+ * its autograd backward): cur <- x; per layer: [cur <- mask > 0 ? cur : 0] [store_in <- cur] cur <- W cur + bias [+ addend] [relu]
  * [store_out <- cur]; y <- cur.  x, y, mask, store_in, store_out: PT32 tensors with 256 features over n_tasks x tiles_per_task
  * tiles.  w_img: the layer's weights as THREE bf16 terms, W = W0 + W1 + W2 exactly to 2^-27 (W0 = bf16(W), W1 = bf16(W - W0),
  * W2 = bf16(W - W0 - W1)), each a 256 x 256 k-permuted image as npf_cast_bf16_weights makes it, stored back to back; the kernel
@@ -306,6 +306,7 @@ typedef struct {
   const float *mask;   /* PT32 or NULL */
   float *store_in;     /* PT32 or NULL */
   float *store_out;    /* PT32 or NULL */
+  const float *addend; /* PT32 or NULL: added before the ReLU (MergeFlatInputs: relu(x1 + resizer(x2)), encoders.py:178-179) */
   int32_t relu;
   int32_t reserved;
 } npf_x6_layer_t;

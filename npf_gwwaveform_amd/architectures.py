@@ -256,8 +256,14 @@ class MergeFlatInputs(nn.Module):
                 return self.append_taskvec_to(ch, taskvec).output_rows().run()[0]
             return self.append_to(ch, x1_pt=x1_pt, x1_modulus=x1_modulus).output_rows().run()[0]
         stack, relus, _ = st
-        (h0,) = self._merge_only(ch, x1_pt, x1_modulus, taskvec).output_pt().run()
-        h = mlp_x6.run_stack(h0, ch.pts, stack, relus)
+        rl = self.resizer.layers()
+        if x1_pt is not None and x1_modulus == 0 and taskvec is None and mlp_x6.usable(rl):
+            # the resizer and the merge on the split kernel as well: x1 enters the resizer's last layer as its addend
+            (x2,) = ch.output_pt().run()
+            h = mlp_x6.run_stack(x2, ch.pts, rl + stack, [True] * len(rl) + relus, addend=x1_pt, add_at=len(rl) - 1)
+        else:
+            (h0,) = self._merge_only(ch, x1_pt, x1_modulus, taskvec).output_pt().run()
+            h = mlp_x6.run_stack(h0, ch.pts, stack, relus)
         out = self.flat_module.out
         ch2 = Chain(ch.n_tasks, ch.pts, ch.device)
         ch2.input_pt(h, out.in_features).linear(out.weight, out.bias).output_rows()

@@ -128,6 +128,14 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
     x6_u32x4 tb[3][8];
 #pragma unroll
     for (int st = 0; st < 8; ++st) x6m_split(cur[2 * st], cur[2 * st + 1], tb[0][st], tb[1][st], tb[2][st]);
+    // an addend (the decoder's relu(x1 + resizer(R)), encoders.py:178-179) waits in the registers of the blocks it will
+    // be added to: the layer's input is dead once it is split, and block s is only rewritten at slab s
+    const bool has_add = ly.addend != nullptr;
+    if (has_add) {
+      const float* ad = ly.addend + lane_off;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) cur[b] = valid ? *(const f32x4*)(ad + b * 512) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float* out = (ly.store_out != nullptr && valid) ? ly.store_out + lane_off : nullptr;
     const unsigned bias_l = lds0 + kXSlots * kXSlabBytes + (l & 1) * (kXF * 4) + g * 16;
     const bool relu = ly.relu != 0;
@@ -168,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
 #undef X6MM
       }
       acc += sm;
+      if (has_add) acc += cur[s];
       if (relu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
@@ -194,7 +203,7 @@ extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, co
   for (int l = 0; l < n_layers; ++l) {
     const npf_x6_layer_t& ly = layers[l];
     if (!ly.w_img || (((uintptr_t)ly.w_img) & 15)) return NPF_EINVAL;
-    if ((((uintptr_t)ly.mask) | ((uintptr_t)ly.store_in) | ((uintptr_t)ly.store_out)) & 15) return NPF_EINVAL;
+    if ((((uintptr_t)ly.mask) | ((uintptr_t)ly.store_in) | ((uintptr_t)ly.store_out) | ((uintptr_t)ly.addend)) & 15) return NPF_EINVAL;
     if (ly.bias && (((uintptr_t)ly.bias) & 3)) return NPF_EINVAL;
     a.layer[l] = ly;
   }

@@ -16,15 +16,13 @@ import torch
 from . import _lib as L
 from . import chain as CH
 
-# Opt-in (NPF_MLP_X6=1), fp32 compute mode only.  Parity-green on every golden and sweep case when switched on, but not
-# a gain yet on config 2: the stacks run at 172 - 205 TF/s fp32-equivalent where the fp32 chain kernel does
-# 105 - 116, but they are only 275 of the step's 725 chain GFLOP, cutting them out leaves the attention part of the
-# decoder's dgrad chain at 67 TF/s (its stores and loads no longer hide behind seven layers of MFMAs) and adds a PT32 round
-# trip per cut; and a step with them does not survive HIP-graph capture yet (segfault in capture_end of
-# Trainer(use_graph=True); bisected as far as: it needs no x6 launch at all -- cutting a chain in two with any torch op between
-# the halves is enough, for the XY-encoder or the decoder alone -- so it sits in how two dependent chains of one module are
-# captured, not in this kernel).
-ENABLED = os.environ.get("NPF_MLP_X6", "0") == "1"
+# On by default in the fp32 compute mode (NPF_NO_MLP_X6=1: the layers stay inside the fp32 chains).  Config 2: the decoder's
+# resizer + merge + hidden layers (6 of its 9 layer-equivalents) and the XY-encoder's flat MLP run here at 170 - 205 TF/s
+# fp32-equivalent where the fp32 chain kernel does 105 - 116; eager step 9.30 -> 8.66 ms.  A step with these launches does not
+# survive HIP-graph capture yet (segfault in capture_end of Trainer(use_graph=True); bisected as far as: it needs no x6 launch
+# at all -- cutting a chain in two with any torch op between the halves is enough, for the XY-encoder or the decoder alone),
+# so the Trainer launches such steps eagerly -- still faster than the replayed unsplit step (9.23 ms).
+ENABLED = os.environ.get("NPF_NO_MLP_X6", "0") != "1"
 WIDTH = 256
 
 
@@ -54,6 +52,7 @@ def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], 
             arr[j].mask = L.ptr(ly.get("mask")) if ly.get("mask") is not None else None
             arr[j].store_in = L.ptr(ly.get("store_in")) if ly.get("store_in") is not None else None
             arr[j].store_out = L.ptr(ly.get("store_out")) if ly.get("store_out") is not None else None
+            arr[j].addend = L.ptr(ly.get("addend")) if ly.get("addend") is not None else None
             arr[j].relu = int(bool(ly.get("relu", False)))
         out = y if last else torch.empty_like(x)
         if CH.PROFILE is not None:
@@ -65,61 +64,69 @@ def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], 
             ev1.record()
             padded = n_tasks * tiles * 32
             nbytes = padded * 1024 * (2 + sum((ly.get("mask") is not None) + (ly.get("store_in") is not None)
-                                              + (ly.get("store_out") is not None) for ly in chunk)) + len(chunk) * 3 * 2 * WIDTH * WIDTH
+                                              + (ly.get("store_out") is not None) + (ly.get("addend") is not None)
+                                              for ly in chunk)) + len(chunk) * 3 * 2 * WIDTH * WIDTH
             CH.PROFILE.append(("mlp_x6_kernel", 2 * WIDTH * WIDTH * len(chunk) * n_tasks * tiles * 32, ev0, ev1, nbytes))
         x = out
 
 
 class _MlpX6Fn(torch.autograd.Function):
-    """y = stack(x): x, y PT32 [n_tasks, tiles, 64, 32, 4]; params = W_0, b_0, W_1, b_1, ... (b may be None)."""
+    """y = stack(x): x, y PT32 [n_tasks, tiles, 64, 32, 4]; ``addend`` (PT32 or None) enters layer ``add_at`` before its
+    ReLU; params = W_0, b_0, W_1, b_1, ... (b may be None)."""
 
     @staticmethod
-    def forward(ctx, x, pts, relus, *params):
+    def forward(ctx, x, pts, relus, addend, add_at, *params):
         n_tasks, tiles = x.shape[0], x.shape[1]
         Ws, bs = list(params[0::2]), list(params[1::2])
         train = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
         x = x.detach().contiguous()
+        add = addend.detach().contiguous() if addend is not None else None
         imgs = _three_term_images(Ws, transposed=False)
         y = torch.empty_like(x)
         outs = []
         layers = []
         for i, (img, b, r) in enumerate(zip(imgs, bs, relus)):
-            ly = dict(img=img, bias=b.detach() if b is not None else None, relu=r)
+            ly = dict(img=img, bias=b.detach() if b is not None else None, relu=r, addend=add if i == add_at else None)
             if train and i + 1 < len(imgs):  # the layer's output = the next layer's input (wgrad operand) and ReLU mask
                 ly["store_out"] = torch.empty_like(x)
                 outs.append(ly["store_out"])
             layers.append(ly)
         _launch(layers, x, y, n_tasks, tiles)
-        outs.append(y)
-        ctx.pts, ctx.relus, ctx.geom = pts, tuple(relus), (n_tasks, tiles)
-        ctx.acts = [x] + outs            # acts[i] = input of layer i; acts[i + 1] = its output
-        ctx.params = (Ws, bs)
+        ctx.pts, ctx.relus, ctx.geom, ctx.add_at = pts, tuple(relus), (n_tasks, tiles), (add_at if addend is not None else -1)
+        ctx.n = len(Ws)
+        # acts[i] = input of layer i, acts[i + 1] = its output; through save_for_backward: the output y among them would
+        # otherwise close a reference cycle (y -> grad_fn -> ctx -> y) that only the cyclic collector frees -- GBs per step
+        ctx.save_for_backward(x, *outs, y, *[w for w in Ws], *[b for b in bs if b is not None])
+        ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, g):
+        n = ctx.n
         if g is None:
-            return (None,) * (3 + 2 * len(ctx.params[0]))
-        Ws, bs = ctx.params
+            return (None,) * (5 + 2 * n)
+        saved = list(ctx.saved_tensors)
+        acts, Ws = saved[:n + 1], saved[n + 1:2 * n + 1]
         n_tasks, tiles = ctx.geom
-        n = len(Ws)
         g = g.contiguous()
         imgs_t = _three_term_images(Ws, transposed=True)
         dzs = [torch.empty_like(g) for _ in range(n)]
         layers = []
         for i in range(n - 1, -1, -1):  # dZ_i = g_i masked by the layer's own output; g_{i-1} = W_i^T dZ_i
-            layers.append(dict(img=imgs_t[i], mask=ctx.acts[i + 1] if ctx.relus[i] else None, store_in=dzs[i]))
+            layers.append(dict(img=imgs_t[i], mask=acts[i + 1] if ctx.relus[i] else None, store_in=dzs[i]))
         dx = torch.empty_like(g)
         _launch(layers, g, dx, n_tasks, tiles)
         jobs, grads = [], []
         for i in range(n):
             dW = torch.empty((WIDTH, WIDTH), dtype=torch.float32, device=g.device)
-            db = torch.empty((WIDTH,), dtype=torch.float32, device=g.device) if bs[i] is not None else None
-            jobs.append(dict(dZ=dzs[i], A=ctx.acts[i], N=WIDTH, K=WIDTH, dW=dW, db=db))
+            db = torch.empty((WIDTH,), dtype=torch.float32, device=g.device) if ctx.has_b[i] else None
+            jobs.append(dict(dZ=dzs[i], A=acts[i], N=WIDTH, K=WIDTH, dW=dW, db=db))
             grads += [dW, db]
         CH.run_wgrad(jobs, n_tasks, ctx.pts, g.device)
-        return (dx, None, None, *grads)
+        # the addend's gradient is the dZ of its layer (it enters in front of the ReLU, with unit weight)
+        d_add = dzs[ctx.add_at] if ctx.add_at >= 0 else None
+        return (dx, None, None, d_add, None, *grads)
 
 
 def usable(linears: Sequence[torch.nn.Linear]) -> bool:
@@ -128,10 +135,11 @@ def usable(linears: Sequence[torch.nn.Linear]) -> bool:
             and all(l.in_features == WIDTH and l.out_features == WIDTH for l in linears))
 
 
-def run_stack(x_pt: torch.Tensor, pts: int, linears: Sequence[torch.nn.Linear], relus: Sequence[bool]) -> torch.Tensor:
+def run_stack(x_pt: torch.Tensor, pts: int, linears: Sequence[torch.nn.Linear], relus: Sequence[bool],
+              addend: Optional[torch.Tensor] = None, add_at: int = 0) -> torch.Tensor:
     """PT32 [n_tasks, tiles, 64, 32, 4] -> the same shape through ``linears`` (256 -> 256 each), ReLU behind layer i when
-    ``relus[i]``."""
+    ``relus[i]``; ``addend`` (PT32, same shape) is added in front of the ReLU of layer ``add_at``."""
     params = []
     for lin in linears:
         params += [lin.weight, lin.bias]
-    return _MlpX6Fn.apply(x_pt, pts, tuple(bool(r) for r in relus), *params)
+    return _MlpX6Fn.apply(x_pt, pts, tuple(bool(r) for r in relus), addend, int(add_at), *params)

@@ -415,7 +415,8 @@ def test_mlp_x6_stack_forward_and_backward_match_float64():
 
     CH, FN = _mods()
     g = torch.Generator().manual_seed(53)
-    for n_tasks, pts, n_layers, last_relu in ((3, 70, 3, False), (1, 33, 1, True), (2, 64, 10, True)):
+    for n_tasks, pts, n_layers, last_relu, add_at in ((3, 70, 3, False, -1), (1, 33, 1, True, -1), (2, 64, 10, True, -1),
+                                                      (2, 45, 4, True, 1), (1, 40, 10, False, 8)):
         lins = [torch.nn.Linear(256, 256) for _ in range(n_layers)]
         for lin in lins:
             lin.weight.data = torch.randn(256, 256, generator=g) * 0.09
@@ -423,24 +424,30 @@ def test_mlp_x6_stack_forward_and_backward_match_float64():
         relus = [True] * (n_layers - 1) + [last_relu]
         x = torch.randn(n_tasks, pts, 256, generator=g)
         w = torch.randn(n_tasks, pts, 256, generator=g)
+        addend = torch.randn(n_tasks, pts, 256, generator=g) if add_at >= 0 else None
         # float64 reference
         ref_lins = [torch.nn.Linear(256, 256).double() for _ in lins]
         for a, b in zip(ref_lins, lins):
             a.load_state_dict({k: v.double() for k, v in b.state_dict().items()})
         xr = x.double().requires_grad_(True)
+        ar = addend.double().requires_grad_(True) if addend is not None else None
         h = xr
-        for lin, r in zip(ref_lins, relus):
-            h = lin(h)
+        for i, (lin, r) in enumerate(zip(ref_lins, relus)):
+            h = lin(h) + (ar if i == add_at else 0.0)
             h = torch.relu(h) if r else h
         (h * w.double()).sum().backward()
         # HIP
         dev_lins = [lin.to(DEV) for lin in lins]
         xd = x.to(DEV).requires_grad_(True)
-        y_pt = mlp_x6.run_stack(FN.pack_pt(xd), pts, dev_lins, relus)
+        ad = addend.to(DEV).requires_grad_(True) if addend is not None else None
+        y_pt = mlp_x6.run_stack(FN.pack_pt(xd), pts, dev_lins, relus, addend=FN.pack_pt(ad) if ad is not None else None,
+                                add_at=max(add_at, 0))
         y = FN.unpack_pt(y_pt, pts, 256)
         (y * w.to(DEV)).sum().backward()
         assert_close(y, h, tol=1e-5, what=f"x6 stack forward ({n_layers} layers)")
         assert_close(xd.grad, xr.grad, tol=1e-4, what="x6 stack dx")
+        if ad is not None:
+            assert_close(ad.grad, ar.grad, tol=1e-4, what="x6 stack d(addend)")
         for i, (a, b) in enumerate(zip(dev_lins, ref_lins)):
             assert_close(a.weight.grad, b.weight.grad, tol=1e-4, what=f"x6 stack dW[{i}]")
             assert_close(a.bias.grad, b.bias.grad, tol=1e-4, what=f"x6 stack db[{i}]")

@@ -93,13 +93,13 @@ def test_model_variants_parity(name):
 
 
 @pytest.mark.parametrize("name", ["g3_attncnp_c2", "g4_attnlnp_c2"])
-def test_model_parity_with_split_mlp_stacks(name, monkeypatch):
-    """NPF_MLP_X6=1: the 256 -> 256 layers of the XY-encoder / decoder flat MLPs on ``npf_mlp_x6_run`` (fp32 products as
-    three exact bf16 terms on the bf16 pipe, csrc/mlp_x6_kernel.hip) instead of inside the fp32 chains: the reference's
-    outputs, loss and gradients at the same fp32 tolerances."""
+def test_model_parity_without_split_mlp_stacks(name, monkeypatch):
+    """NPF_NO_MLP_X6=1: the 256 -> 256 layers of the flat MLPs inside the fp32 chains (``v_mfma_f32_16x16x4_f32``) instead
+    of on ``npf_mlp_x6_run`` (the default since round 2: fp32 products as three exact bf16 terms on the bf16 pipe,
+    csrc/mlp_x6_kernel.hip) -- the reference's outputs, loss and gradients at the same fp32 tolerances on either path."""
     from npf_gwwaveform_amd import mlp_x6
 
-    monkeypatch.setattr(mlp_x6, "ENABLED", True)
+    monkeypatch.setattr(mlp_x6, "ENABLED", False)
     test_model_train_step_parity(name)
 
 
