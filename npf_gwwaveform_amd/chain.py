@@ -901,6 +901,14 @@ class _ChainFn(torch.autograd.Function):
             else:  # pragma: no cover
                 raise AssertionError(k)
         prog.launch()
+        # A saved tensor that is also an output (a chain ending in a ReLU layer: its output doubles as the mask) goes
+        # through save_for_backward: kept in the dict it would close a reference cycle (output -> grad_fn -> ctx -> output)
+        # that only the cyclic collector frees -- a point-sized tensor leaked per step until then
+        out_pos = {id(o): j for j, o in enumerate(outputs)}
+        ctx.alias_keys = [key for key, t in saved.items() if id(t) in out_pos]
+        ctx.save_for_backward(*[saved[key] for key in ctx.alias_keys])
+        for key in ctx.alias_keys:
+            del saved[key]
         ctx.chain, ctx.saved, ctx.T, ctx.needs_grad, ctx.upstream_before = chain, saved, T, needs_grad, upstream_before
         ctx.bf16 = bf16
         ctx.train = train
@@ -912,7 +920,8 @@ class _ChainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         chain: Chain = ctx.chain
-        saved, T, needs_grad, upstream_before = ctx.saved, ctx.T, ctx.needs_grad, ctx.upstream_before
+        saved, T, needs_grad, upstream_before = dict(ctx.saved), ctx.T, ctx.needs_grad, ctx.upstream_before
+        saved.update(zip(ctx.alias_keys, ctx.saved_tensors))
         dev = chain.device
         prog = Program(chain.n_tasks, chain.pts, chain.wg_per_task)
         grads: List[Optional[torch.Tensor]] = [None] * len(T)

@@ -17,11 +17,8 @@ from . import _lib as L
 from . import chain as CH
 
 # On by default in the fp32 compute mode (NPF_NO_MLP_X6=1: the layers stay inside the fp32 chains).  Config 2: the decoder's
-# resizer + merge + hidden layers (6 of its 9 layer-equivalents) and the XY-encoder's flat MLP run here at 170 - 205 TF/s
-# fp32-equivalent where the fp32 chain kernel does 105 - 116; eager step 9.30 -> 8.66 ms.  A step with these launches does not
-# survive HIP-graph capture yet (segfault in capture_end of Trainer(use_graph=True); bisected as far as: it needs no x6 launch
-# at all -- cutting a chain in two with any torch op between the halves is enough, for the XY-encoder or the decoder alone),
-# so the Trainer launches such steps eagerly -- still faster than the replayed unsplit step (9.23 ms).
+# resizer + merge + hidden layers (6 of its 9 layer-equivalents) and the XY-encoder's flat module run here at 175 - 217 TF/s
+# fp32-equivalent where the fp32 chain kernel does 105 - 116; step 9.23 -> 8.7 - 8.9 ms.
 ENABLED = os.environ.get("NPF_NO_MLP_X6", "0") != "1"
 WIDTH = 256
 

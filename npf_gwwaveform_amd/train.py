@@ -63,10 +63,6 @@ class Trainer:
         self.flat = FlatParameters(model.parameters())
         self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
         self.use_graph = bool(use_graph) and self.flat.flat.is_cuda and self.reducer.world == 1
-        if self.use_graph and self._split_stacks(model):
-            # a step whose flat MLPs run on npf_mlp_x6_run (mlp_x6.py) does not survive HIP-graph capture yet, and is
-            # faster launched eagerly than the unsplit step is replayed (config 2: 8.66 against 9.23 ms)
-            self.use_graph = False
         if self.use_graph and hasattr(getattr(model, "n_z_samples_train", None), "rvs"):
             raise ValueError("use_graph=True freezes the step at capture time, but this model draws a random number of "
                              "latent samples per forward (n_z_samples_train is a random variable)")
@@ -105,21 +101,6 @@ class Trainer:
                 st["step"].copy_(step_dev.reshape(()).to(st["step"].device))
             else:
                 st["step"] = float(step_dev.item())
-
-    @staticmethod
-    def _split_stacks(model) -> bool:
-        """Does any merge module of ``model`` put its 256-wide layers on the split kernel (fp32 mode, NPF_NO_MLP_X6 unset)."""
-        from . import chain as _chain
-        from .architectures import MergeFlatInputs
-
-        if _chain.COMPUTE_DTYPE != "fp32":
-            return False
-        was = model.training
-        model.train()
-        try:
-            return any(isinstance(m, MergeFlatInputs) and m._x6_stack() is not None for m in model.modules())
-        finally:
-            model.train(was)
 
     def step(self, batch: dict, eager: bool = False) -> torch.Tensor:
         """One optimisation step; ``eager``: bypass the captured graph for this step (instrumented runs)."""
