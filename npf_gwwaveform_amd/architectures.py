@@ -282,8 +282,18 @@ class MergeFlatInputs(nn.Module):
                 (h0,) = self._merge_only(ch, x1_pt, kw.get("x1_modulus", 0)).output_pt().run()
                 h = mlp_x6.run_stack(h0, pts, stack, relus)
                 out = self.flat_module.out
-                if covers_out and not with_tr:
-                    return PTensor(h, pts, out.out_features)
+                if covers_out:
+                    if not with_tr:
+                        return PTensor(h, pts, out.out_features)
+                    from . import chain as _chain
+
+                    if _chain.COMPUTE_DTYPE == "fp32":
+                        # only the feature-major copy is missing: a chain that reads h and stores it transposed (no PT32
+                        # output of its own: h itself is the tensor, and its gradient goes straight to the stack)
+                        ch2 = Chain(n_tasks, pts, ch.device)
+                        ch2.input_pt(h.detach(), out.out_features).store_tr()
+                        (tr,) = ch2.run()
+                        return PTensor(h, pts, out.out_features, tr=tr)
                 ch2 = Chain(n_tasks, pts, ch.device)
                 ch2.input_pt(h, out.in_features)
                 if not covers_out:

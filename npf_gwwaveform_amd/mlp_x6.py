@@ -23,19 +23,20 @@ ENABLED = os.environ.get("NPF_NO_MLP_X6", "0") != "1"
 WIDTH = 256
 
 
-def _three_term_images(Ws: Sequence[torch.Tensor], transposed: bool) -> List[torch.Tensor]:
-    """Per weight matrix [256, 256] its three-term image [3, 256, 256] bf16 (k-permuted like ``npf_cast_bf16_weights``;
-    of W^T when ``transposed``): W0 = bf16(W), W1 = bf16(W - W0), W2 = bf16(W - W0 - W1), each exactly representable, so
-    the cast kernel only permutes."""
+def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List[List[torch.Tensor]]:
+    """Per weight matrix [256, 256] and per kind (1: of W, 2: of W^T) its three-term image [3, 256, 256] bf16 (k-permuted like
+    ``npf_cast_bf16_weights``): W0 = bf16(W), W1 = bf16(W - W0), W2 = bf16(W - W0 - W1), each exactly representable, so the cast
+    kernel only permutes.  One batch of torch ops and one ``npf_prepare_weights`` launch per 32 images for all of them."""
     W = torch.stack([w.detach() for w in Ws])                     # [n, 256, 256]
     t0 = W.to(torch.bfloat16).float()
     r1 = W - t0
     t1 = r1.to(torch.bfloat16).float()
     t2 = (r1 - t1).to(torch.bfloat16).float()
     terms = torch.stack([t0, t1, t2], dim=1).contiguous()         # [n, 3, 256, 256] fp32, bf16-representable
-    specs = [(terms[i, s], 2 if transposed else 1) for i in range(len(Ws)) for s in range(3)]
-    imgs = CH.prepare_weights(specs)                              # 3 n images [256, 256] bf16
-    return [torch.stack(imgs[3 * i:3 * i + 3]).contiguous() for i in range(len(Ws))]
+    specs = [(terms[i, s], kind) for kind in kinds for i in range(len(Ws)) for s in range(3)]
+    imgs = CH.prepare_weights(specs)
+    n = len(Ws)
+    return [[torch.stack(imgs[3 * (k * n + i):3 * (k * n + i) + 3]).contiguous() for i in range(n)] for k in range(len(kinds))]
 
 
 def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], n_tasks: int, tiles: int) -> None:
@@ -78,7 +79,8 @@ class _MlpX6Fn(torch.autograd.Function):
         train = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
         x = x.detach().contiguous()
         add = addend.detach().contiguous() if addend is not None else None
-        imgs = _three_term_images(Ws, transposed=False)
+        both = _three_term_images(Ws, (1, 2) if train else (1,))  # (the images of W^T for the dgrad in the same batch)
+        imgs = both[0]
         y = torch.empty_like(x)
         outs = []
         layers = []
@@ -93,7 +95,7 @@ class _MlpX6Fn(torch.autograd.Function):
         ctx.n = len(Ws)
         # acts[i] = input of layer i, acts[i + 1] = its output; through save_for_backward: the output y among them would
         # otherwise close a reference cycle (y -> grad_fn -> ctx -> y) that only the cyclic collector frees -- GBs per step
-        ctx.save_for_backward(x, *outs, y, *[w for w in Ws], *[b for b in bs if b is not None])
+        ctx.save_for_backward(x, *outs, y, *(both[1] if train else []))
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
         return y
@@ -104,10 +106,9 @@ class _MlpX6Fn(torch.autograd.Function):
         if g is None:
             return (None,) * (5 + 2 * n)
         saved = list(ctx.saved_tensors)
-        acts, Ws = saved[:n + 1], saved[n + 1:2 * n + 1]
+        acts, imgs_t = saved[:n + 1], saved[n + 1:2 * n + 1]
         n_tasks, tiles = ctx.geom
         g = g.contiguous()
-        imgs_t = _three_term_images(Ws, transposed=True)
         dzs = [torch.empty_like(g) for _ in range(n)]
         layers = []
         for i in range(n - 1, -1, -1):  # dZ_i = g_i masked by the layer's own output; g_{i-1} = W_i^T dZ_i
