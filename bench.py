@@ -471,6 +471,12 @@ def main_train(args, rank, world, dev, sync, rehearsal):
     def step(i):
         return trainer.step(batches[i % len(batches)])
 
+    if use_graph:
+        # set-up, not warm-up: the Trainer launches its first three steps eagerly (allocator, lazy initialisations) and
+        # captures the HIP graph on the fourth -- with --warmup < 4 the capture would otherwise land in the timed region
+        for i in range(4):
+            step(i)
+        sync()
     for i in range(args.warmup):
         step(i)
     elapsed, spread, loss = timed_region(step, args.steps, sync)
