@@ -7,13 +7,13 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$1"; shift
 mkdir -p /tmp/npfobj
 CS="$ROOT/npf_gwwaveform_amd/csrc"
-for f in chain_kernel head_kernels layout_kernels; do
+for f in chain_kernel head_kernels layout_kernels mlp_x6_kernel; do
   if [ ! -f /tmp/npfobj/$f.o ] || [ "$CS/$f.hip" -nt /tmp/npfobj/$f.o ] || [ "$CS/npf_common.hpp" -nt /tmp/npfobj/$f.o ] || [ "$ROOT/include/npf_hip.h" -nt /tmp/npfobj/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I "$ROOT/include" -I "$CS" -c "$CS/$f.hip" -o /tmp/npfobj/$f.o &
   fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -I "$ROOT/include" -I "$CS" -c "$CS/wgrad_kernel.hip" -o /tmp/npfobj/wgrad_$$.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared /tmp/npfobj/chain_kernel.o /tmp/npfobj/head_kernels.o /tmp/npfobj/layout_kernels.o /tmp/npfobj/wgrad_$$.o -o "$OUT"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared /tmp/npfobj/chain_kernel.o /tmp/npfobj/head_kernels.o /tmp/npfobj/layout_kernels.o /tmp/npfobj/mlp_x6_kernel.o /tmp/npfobj/wgrad_$$.o -o "$OUT"
 rm -f /tmp/npfobj/wgrad_$$.o
 echo "built $OUT"
