@@ -307,6 +307,11 @@ typedef struct {
   float *store_in;     /* PT32 or NULL */
   float *store_out;    /* PT32 or NULL */
   const float *addend; /* PT32 or NULL: added before the ReLU (MergeFlatInputs: relu(x1 + resizer(x2)), encoders.py:178-179) */
+  /* where the layer's output is positive, as bits: one uint64 per lane and half tile ([tiles][2][64], bit 4 b + e = the
+   * lane's block b, element e) -- written by a forward layer (store_bits), read by the dgrad of the same layer (mask_bits)
+   * in place of `mask`: 8 bytes per 64 values */
+  unsigned long long *store_bits;
+  const unsigned long long *mask_bits;
   int32_t relu;
   int32_t reserved;
 } npf_x6_layer_t;

@@ -68,7 +68,8 @@ NPF_X6_MAX_LAYERS = 8
 
 class NpfX6Layer(C.Structure):
     _fields_ = [("w_img", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("store_in", C.c_void_p),
-                ("store_out", C.c_void_p), ("addend", C.c_void_p), ("relu", C.c_int32), ("reserved", C.c_int32)]
+                ("store_out", C.c_void_p), ("addend", C.c_void_p), ("store_bits", C.c_void_p), ("mask_bits", C.c_void_p),
+                ("relu", C.c_int32), ("reserved", C.c_int32)]
 
 
 assert C.sizeof(NpfOp) == 80 and C.sizeof(NpfProgram) == 32 + 80 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 72 and C.sizeof(NpfWprepJob) == 32

@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
   // this lane's float4 column in its tile of a PT32 tensor with 256 features: block b at + (4 b + g) * 128 floats
   const size_t lane_off = (size_t)(valid ? tile : 0) * (kXF * 32) + (size_t)(16 * (wave & 1) + p) * 4 + (size_t)g * 128;
 
+  // sign-bit tensors: one 64-bit word per lane and half tile, [tile][half][64 lanes]
+  const size_t bits_off = ((size_t)(valid ? tile : 0) * 2 + (wave & 1)) * 64 + lane;
   f32x4 cur[16];
   {
     const float* x = a.x + lane_off;
@@ -117,6 +119,15 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
         for (int e = 0; e < 4; ++e) cur[b][e] = v[e] > 0.f ? cur[b][e] : 0.f;
       }
     }
+    // the same from the 64 sign bits per lane the forward pass left (bit 4 b + e = block b, element e): 8 bytes per lane
+    // and layer instead of 256
+    if (ly.mask_bits != nullptr && valid) {
+      const unsigned long long w = ly.mask_bits[bits_off];
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur[b][e] = ((w >> (4 * b + e)) & 1ull) ? cur[b][e] : 0.f;
+    }
     if (ly.store_in != nullptr && valid) {
       float* d = ly.store_in + lane_off;
 #pragma unroll
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
     float* out = (ly.store_out != nullptr && valid) ? ly.store_out + lane_off : nullptr;
     const unsigned bias_l = lds0 + kXSlots * kXSlabBytes + (l & 1) * (kXF * 4) + g * 16;
     const bool relu = ly.relu != 0;
+    unsigned long long pos_bits = 0ull;  // where this layer's output is positive (store_bits)
 #pragma unroll
     for (int s = 0; s < kXSlabs; ++s) {
       const int S = l * kXSlabs + s;
@@ -183,8 +195,11 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
       }
       cur[s] = acc;  // (block s of the input is dead: its terms are in tb)
       if (out != nullptr) __builtin_nontemporal_store(acc, (f32x4*)(out + s * 512));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pos_bits |= (unsigned long long)(acc[e] > 0.f) << (4 * s + e);
       slot = (slot + 1) % kXSlots;
     }
+    if (ly.store_bits != nullptr && valid) ly.store_bits[bits_off] = pos_bits;
   }
   if (valid && a.y != nullptr) {
     float* y = a.y + lane_off;
@@ -204,6 +219,7 @@ extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, co
     const npf_x6_layer_t& ly = layers[l];
     if (!ly.w_img || (((uintptr_t)ly.w_img) & 15)) return NPF_EINVAL;
     if ((((uintptr_t)ly.mask) | ((uintptr_t)ly.store_in) | ((uintptr_t)ly.store_out) | ((uintptr_t)ly.addend)) & 15) return NPF_EINVAL;
+    if ((((uintptr_t)ly.mask_bits) | ((uintptr_t)ly.store_bits)) & 7) return NPF_EINVAL;
     if (ly.bias && (((uintptr_t)ly.bias) & 3)) return NPF_EINVAL;
     a.layer[l] = ly;
   }

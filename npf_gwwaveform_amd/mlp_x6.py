@@ -51,6 +51,8 @@ def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], 
             arr[j].store_in = L.ptr(ly.get("store_in")) if ly.get("store_in") is not None else None
             arr[j].store_out = L.ptr(ly.get("store_out")) if ly.get("store_out") is not None else None
             arr[j].addend = L.ptr(ly.get("addend")) if ly.get("addend") is not None else None
+            arr[j].store_bits = ly["store_bits"].data_ptr() if ly.get("store_bits") is not None else None
+            arr[j].mask_bits = ly["mask_bits"].data_ptr() if ly.get("mask_bits") is not None else None
             arr[j].relu = int(bool(ly.get("relu", False)))
         out = y if last else torch.empty_like(x)
         if CH.PROFILE is not None:
@@ -61,7 +63,8 @@ def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], 
         if CH.PROFILE is not None:
             ev1.record()
             padded = n_tasks * tiles * 32
-            nbytes = padded * 1024 * (2 + sum((ly.get("mask") is not None) + (ly.get("store_in") is not None)
+            nbytes = padded * 32 * sum((ly.get("mask_bits") is not None) + (ly.get("store_bits") is not None) for ly in chunk)
+            nbytes += padded * 1024 * (2 + sum((ly.get("mask") is not None) + (ly.get("store_in") is not None)
                                               + (ly.get("store_out") is not None) + (ly.get("addend") is not None)
                                               for ly in chunk)) + len(chunk) * 3 * 2 * WIDTH * WIDTH
             CH.PROFILE.append(("mlp_x6_kernel", 2 * WIDTH * WIDTH * len(chunk) * n_tasks * tiles * 32, ev0, ev1, nbytes))
@@ -82,20 +85,23 @@ class _MlpX6Fn(torch.autograd.Function):
         both = _three_term_images(Ws, (1, 2) if train else (1,))  # (the images of W^T for the dgrad in the same batch)
         imgs = both[0]
         y = torch.empty_like(x)
-        outs = []
+        outs, bits = [], []
         layers = []
         for i, (img, b, r) in enumerate(zip(imgs, bs, relus)):
             ly = dict(img=img, bias=b.detach() if b is not None else None, relu=r, addend=add if i == add_at else None)
-            if train and i + 1 < len(imgs):  # the layer's output = the next layer's input (wgrad operand) and ReLU mask
+            if train and i + 1 < len(imgs):  # the layer's output = the next layer's input (the weight gradient's operand)
                 ly["store_out"] = torch.empty_like(x)
                 outs.append(ly["store_out"])
+            if train and r:  # where it is positive, as bits: what the dgrad needs of it (8 bytes per lane instead of 256)
+                ly["store_bits"] = torch.empty((n_tasks, tiles, 2, 64), dtype=torch.int64, device=x.device)
+                bits.append(ly["store_bits"])
             layers.append(ly)
         _launch(layers, x, y, n_tasks, tiles)
         ctx.pts, ctx.relus, ctx.geom, ctx.add_at = pts, tuple(relus), (n_tasks, tiles), (add_at if addend is not None else -1)
         ctx.n = len(Ws)
         # acts[i] = input of layer i, acts[i + 1] = its output; through save_for_backward: the output y among them would
         # otherwise close a reference cycle (y -> grad_fn -> ctx -> y) that only the cyclic collector frees -- GBs per step
-        ctx.save_for_backward(x, *outs, y, *(both[1] if train else []))
+        ctx.save_for_backward(x, *outs, y, *(both[1] if train else []), *bits)
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
         return y
@@ -106,13 +112,14 @@ class _MlpX6Fn(torch.autograd.Function):
         if g is None:
             return (None,) * (5 + 2 * n)
         saved = list(ctx.saved_tensors)
-        acts, imgs_t = saved[:n + 1], saved[n + 1:2 * n + 1]
+        acts, imgs_t, bits = saved[:n + 1], saved[n + 1:2 * n + 1], saved[2 * n + 1:]
+        bit_of = dict(zip([i for i in range(n) if ctx.relus[i]], bits))
         n_tasks, tiles = ctx.geom
         g = g.contiguous()
         dzs = [torch.empty_like(g) for _ in range(n)]
         layers = []
         for i in range(n - 1, -1, -1):  # dZ_i = g_i masked by the layer's own output; g_{i-1} = W_i^T dZ_i
-            layers.append(dict(img=imgs_t[i], mask=acts[i + 1] if ctx.relus[i] else None, store_in=dzs[i]))
+            layers.append(dict(img=imgs_t[i], mask_bits=bit_of.get(i), store_in=dzs[i]))
         dx = torch.empty_like(g)
         _launch(layers, g, dx, n_tasks, tiles)
         jobs, grads = [], []
