@@ -232,6 +232,13 @@ class MergeFlatInputs(nn.Module):
             stack, relus = stack + [fm.out], relus + [False]
         return stack, relus, covers_out
 
+    def x6_resizer_ok(self, x1_modulus: int = 0) -> bool:
+        """Will ``finish_rows`` put the resizer and the merge on the split kernel too (x1 as the addend of its last layer)."""
+        from . import mlp_x6
+
+        st = self._x6_stack()
+        return st is not None and not st[2] and x1_modulus == 0 and mlp_x6.usable(self.resizer.layers())
+
     def _merge_only(self, ch: Chain, x1_pt=None, x1_modulus: int = 0, taskvec=None) -> Chain:
         """cur <- relu(x1 + resizer(x2)): ``x1_pt`` with cur = x2, or ``taskvec`` (x2 one vector per task) with cur = x1."""
         if taskvec is not None:
@@ -259,7 +266,10 @@ class MergeFlatInputs(nn.Module):
         rl = self.resizer.layers()
         if x1_pt is not None and x1_modulus == 0 and taskvec is None and mlp_x6.usable(rl):
             # the resizer and the merge on the split kernel as well: x1 enters the resizer's last layer as its addend
-            (x2,) = ch.output_pt().run()
+            outs = ch.output_pt().run()
+            x2 = outs[-1]
+            if getattr(ch, "x1_tapped", False):  # (x1 came through the chain: its gradient goes back into that chain's dgrad)
+                x1_pt = outs[0]
             h = mlp_x6.run_stack(x2, ch.pts, rl + stack, [True] * len(rl) + relus, addend=x1_pt, add_at=len(rl) - 1)
         else:
             (h0,) = self._merge_only(ch, x1_pt, x1_modulus, taskvec).output_pt().run()

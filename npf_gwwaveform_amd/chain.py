@@ -677,8 +677,13 @@ class Chain:
         return self
 
     # ---- outputs
-    def tap(self) -> "Chain":
-        self.steps.append(_Step("tap", {}, {"F": self.F}))
+    def tap(self, alias_input: bool = False) -> "Chain":
+        """Extra output: cur at this point.  ``alias_input``: directly behind the chain's ``input_pt`` (no modulus) the output IS
+        the input tensor (no copy) -- a way to hand the same tensor on to a later consumer such that its gradient comes back into
+        THIS chain's dgrad launch and is added there, instead of autograd summing two point-sized tensors in a pass of its own."""
+        if alias_input and not (len(self.steps) == 1 and self.steps[0].kind == "input_pt" and self.steps[0].a["mod"] == 0):
+            raise ValueError("tap(alias_input=True) goes directly behind input_pt (modulus 0)")
+        self.steps.append(_Step("tap", {}, {"F": self.F, "alias": bool(alias_input)}))
         return self
 
     def store_tr(self) -> "Chain":
@@ -889,6 +894,8 @@ class _ChainFn(torch.autograd.Function):
                 (prog.store_wb if k == "store_wb" else prog.store_trb)(o, a["F"])
                 outputs.append(o)
                 non_diff.append(o)
+            elif k == "tap" and a.get("alias"):
+                outputs.append(tensors[chain.steps[0].t["x"]])  # the input itself (autograd makes the output a view of it)
             elif k in ("tap", "output_pt"):
                 # an output must own its storage: never alias an input tensor
                 if backed is not None and any(backed is t for t in T):

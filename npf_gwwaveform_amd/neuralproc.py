@@ -452,7 +452,7 @@ class AttnCNP(NeuralProcessFamily):
             return None
         return self._xyenc_pt(X_enc, Y)
 
-    def _attend_into(self, ch, Xc_pt, R, Xt_pt, C, T):
+    def _attend_into(self, ch, Xc_pt, R, Xt_pt, C, T, tap_x1: bool = False):
         """cur of ``ch`` <- attention of the targets over the context (attnnp.py:118-131): fused into
         the chain while a score row fits the registers, blocked (attention_long.py) beyond that."""
         from . import chain as _chain
@@ -469,6 +469,11 @@ class AttnCNP(NeuralProcessFamily):
                 ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, keys_tr=Xc_pt.tr, values_tr=R.tr), self.r_dim)
         elif self.attender.fits_fused(C):
             ch.input_pt(Xt_pt.t, self.x_transf_dim)
+            if tap_x1:
+                # the encoded targets are the attention's queries here and the decoder's x1 on the split kernel next: handed on
+                # through this chain, both gradients meet in its dgrad launch (MergeFlatInputs.finish_rows)
+                ch.tap(alias_input=True)
+                ch.x1_tapped = True
             self.attender.append_to(ch, Xc_pt.t, R.t, C, keys_tr=Xc_pt.tr, values_tr=R.tr)
         else:
             ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, keys_tr=Xc_pt.tr, values_tr=R.tr), self.r_dim)
@@ -479,7 +484,7 @@ class AttnCNP(NeuralProcessFamily):
         if C == 0:
             ch.input_pt(torch.zeros(pt_shape(B, T, self.r_dim), device=Xt_pt.t.device), self.r_dim)
         else:
-            self._attend_into(ch, Xc_pt, R, Xt_pt, C, T)
+            self._attend_into(ch, Xc_pt, R, Xt_pt, C, T, tap_x1=self.decoder.x6_resizer_ok())
         return self.decoder.finish_rows(ch, x1_pt=Xt_pt.t)
 
 
