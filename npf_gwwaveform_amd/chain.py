@@ -499,12 +499,14 @@ def cast_bf16_weights(W: torch.Tensor, transposed: bool = False) -> torch.Tensor
     return out
 
 
-def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]]) -> List[torch.Tensor]:
+def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]], dsts: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
     """``npf_prepare_weights``: for every (W [N, K] row-major with unit column stride, kind) one output, all in one
     launch per 32 matrices -- kind 0: W^T (fp32 [K, N]); 1: the bf16 image of W; 2: the bf16 image of W^T; 5 / 6: images 1 / 2
     with their rows zero-padded to 256 inputs (PAD_SMALL_K)."""
     outs: List[torch.Tensor] = []
     lib = L.load()
+    if dsts is not None:  # (``dsts``: write the images into these contiguous tensors -- e.g. slices of one buffer -- instead)
+        assert len(dsts) == len(specs) and os.environ.get("NPF_NO_BATCH_PREP") != "1"
     if os.environ.get("NPF_NO_BATCH_PREP") == "1":  # debug switch: one launch per matrix
         if any(kind & 4 for _, kind in specs):
             raise RuntimeError("NPF_NO_BATCH_PREP needs NPF_NO_PAD_SMALL_K=1 as well")
@@ -517,10 +519,16 @@ def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]]) -> List[torch.Ten
             if W.stride(1) != 1 or W.dtype != torch.float32:
                 raise ValueError("weight rows must be contiguous fp32")
             if kind == 0:
-                out = torch.empty((K, N), dtype=torch.float32, device=W.device)
+                shape, dt = (K, N), torch.float32
             else:
                 rows, cols = (K, N) if kind & 3 == 2 else (N, K)
-                out = torch.empty((rows, 256 if kind & 4 else pad32(cols)), dtype=torch.bfloat16, device=W.device)
+                shape, dt = (rows, 256 if kind & 4 else pad32(cols)), torch.bfloat16
+            if dsts is not None:
+                out = dsts[i0 + j]
+                if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous():
+                    raise ValueError(f"prepare_weights: destination {tuple(out.shape)} {out.dtype} for an image {shape} {dt}")
+            else:
+                out = torch.empty(shape, dtype=dt, device=W.device)
             arr[j].src, arr[j].dst = L.ptr(W, strided=True), out.data_ptr()
             arr[j].n_rows, arr[j].n_cols, arr[j].ld, arr[j].kind = N, K, W.stride(0), kind
             outs.append(out)

@@ -33,10 +33,11 @@ def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List
     t1 = r1.to(torch.bfloat16).float()
     t2 = (r1 - t1).to(torch.bfloat16).float()
     terms = torch.stack([t0, t1, t2], dim=1).contiguous()         # [n, 3, 256, 256] fp32, bf16-representable
-    specs = [(terms[i, s], kind) for kind in kinds for i in range(len(Ws)) for s in range(3)]
-    imgs = CH.prepare_weights(specs)
     n = len(Ws)
-    return [[torch.stack(imgs[3 * (k * n + i):3 * (k * n + i) + 3]).contiguous() for i in range(n)] for k in range(len(kinds))]
+    buf = torch.empty((len(kinds), n, 3, WIDTH, WIDTH), dtype=torch.bfloat16, device=W.device)  # (the images land in place)
+    specs = [(terms[i, s], kind) for kind in kinds for i in range(n) for s in range(3)]
+    CH.prepare_weights(specs, dsts=[buf[k, i, s] for k in range(len(kinds)) for i in range(n) for s in range(3)])
+    return [[buf[k, i] for i in range(n)] for k in range(len(kinds))]
 
 
 def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], n_tasks: int, tiles: int) -> None:
