@@ -278,6 +278,8 @@ int npf_cast_bf16_weights(const float *src, int32_t n_rows, int32_t n_cols, int3
 /* Batched weight preparation: up to NPF_MAX_WPREP_JOBS of the two functions above in ONE launch (a chain's
  * dgrad needs W^T -- or, in the bf16 mode, an image -- of every layer; one 5 us launch per layer otherwise).
  * kind: 0 = fp32 transpose (as npf_transpose, src row stride ld), 1 = bf16 image, 2 = bf16 image of src^T;
+ * 1 / 2 + 16 t, t = 1..3: the same image of term t - 1 of the exact three-term split of src (x0 = bf16(x), x1 = bf16(x - x0),
+ * x2 = bf16(x - x0 - x1)) -- the weights of npf_mlp_x6_run;
  * 5 / 6 = kinds 1 / 2 with every image row zero-padded to 256 inputs (a layer with <= 32 real inputs whose remaining
  * input registers are known to be zero then runs as a 256-input layer on the pipelined path). */
 typedef struct npf_wprep_job {

@@ -521,7 +521,7 @@ def prepare_weights(specs: Sequence[Tuple[torch.Tensor, int]], dsts: Optional[Se
             if kind == 0:
                 shape, dt = (K, N), torch.float32
             else:
-                rows, cols = (K, N) if kind & 3 == 2 else (N, K)
+                rows, cols = (K, N) if kind & 3 == 2 else (N, K)   # (kind bits 4-5: a term of the three-term split)
                 shape, dt = (rows, 256 if kind & 4 else pad32(cols)), torch.bfloat16
             if dsts is not None:
                 out = dsts[i0 + j]

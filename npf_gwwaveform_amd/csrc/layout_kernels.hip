@@ -165,6 +165,9 @@ __global__ void prepare_weights_kernel(const WprepJobs J) {
   } else {
     unsigned short* __restrict__ dst = (unsigned short*)jb.dst;
     const bool transposed = (jb.kind & 3) == 2;
+    // kind bits 4-5: 0 = the rounded value; t = 1..3: term t - 1 of the exact three-term split (x0 = bf16(x), x1 = bf16(x - x0),
+    // x2 = bf16(x - x0 - x1); the subtractions are exact in fp32) that the split-product kernels multiply with
+    const int term = (jb.kind >> 4) & 3;
     const int rows = transposed ? jb.n_cols : jb.n_rows, cols = transposed ? jb.n_rows : jb.n_cols, ld = jb.ld;
     const int Kp = (jb.kind & 4) ? 256 : ((cols + 31) >> 5) * 32;  // kinds 5, 6: rows zero-padded to 256 inputs
     const size_t total = (size_t)rows * Kp;
@@ -174,6 +177,7 @@ __global__ void prepare_weights_kernel(const WprepJobs J) {
       const int c = 32 * sgrp + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
       float v = 0.f;
       if (c < cols) v = transposed ? src[(size_t)c * ld + r] : src[(size_t)r * ld + c];
+      for (int t = 1; t < term; ++t) v -= (float)(__bf16)v;
       const __bf16 b = (__bf16)v;
       dst[idx] = __builtin_bit_cast(unsigned short, b);
     }
@@ -302,7 +306,8 @@ extern "C" int npf_prepare_weights(const npf_wprep_job_t* jobs, int32_t n_jobs, 
   size_t most = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const npf_wprep_job_t& b = jobs[j];
-    const bool kind_ok = (b.kind >= 0 && b.kind <= 2) || b.kind == 5 || b.kind == 6;
+    const int base = b.kind & 15, term = b.kind >> 4;
+    const bool kind_ok = b.kind >= 0 && ((term == 0 && (base <= 2 || base == 5 || base == 6)) || (term >= 1 && term <= 3 && (base == 1 || base == 2)));
     if (!b.src || !b.dst || b.n_rows <= 0 || b.n_cols <= 0 || b.ld < b.n_cols || !kind_ok) return NPF_EINVAL;
     if (b.kind != 0 && (((uintptr_t)b.dst) & 15)) return NPF_EINVAL;
     if ((b.kind == 5 && b.n_cols > 256) || (b.kind == 6 && b.n_rows > 256)) return NPF_EINVAL;  // (the image's inputs)

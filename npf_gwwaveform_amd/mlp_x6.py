@@ -25,17 +25,11 @@ WIDTH = 256
 
 def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List[List[torch.Tensor]]:
     """Per weight matrix [256, 256] and per kind (1: of W, 2: of W^T) its three-term image [3, 256, 256] bf16 (k-permuted like
-    ``npf_cast_bf16_weights``): W0 = bf16(W), W1 = bf16(W - W0), W2 = bf16(W - W0 - W1), each exactly representable, so the cast
-    kernel only permutes.  One batch of torch ops and one ``npf_prepare_weights`` launch per 32 images for all of them."""
-    W = torch.stack([w.detach() for w in Ws])                     # [n, 256, 256]
-    t0 = W.to(torch.bfloat16).float()
-    r1 = W - t0
-    t1 = r1.to(torch.bfloat16).float()
-    t2 = (r1 - t1).to(torch.bfloat16).float()
-    terms = torch.stack([t0, t1, t2], dim=1).contiguous()         # [n, 3, 256, 256] fp32, bf16-representable
-    n = len(Ws)
-    buf = torch.empty((len(kinds), n, 3, WIDTH, WIDTH), dtype=torch.bfloat16, device=W.device)  # (the images land in place)
-    specs = [(terms[i, s], kind) for kind in kinds for i in range(n) for s in range(3)]
+    ``npf_cast_bf16_weights``): W0 = bf16(W), W1 = bf16(W - W0), W2 = bf16(W - W0 - W1), split and permuted by
+    ``npf_prepare_weights`` (kinds 1 / 2 + 16 (s + 1)), one launch per 32 images, written in place."""
+    n, dev = len(Ws), Ws[0].device
+    buf = torch.empty((len(kinds), n, 3, WIDTH, WIDTH), dtype=torch.bfloat16, device=dev)  # (the images land in place)
+    specs = [(Ws[i].detach(), kind | ((s + 1) << 4)) for kind in kinds for i in range(n) for s in range(3)]
     CH.prepare_weights(specs, dsts=[buf[k, i, s] for k in range(len(kinds)) for i in range(n) for s in range(3)])
     return [[buf[k, i] for i in range(n)] for k in range(len(kinds))]
 
