@@ -13,6 +13,12 @@
 // slabs of 16 output rows x 3 terms (24 KiB) through a three-slot ring: slab S + 2 is in flight while slab S multiplies, one
 // counted s_waitcnt vmcnt + one barrier per slab.  Measured standalone (tools/experiments/x6_mlp_probe.hip): 8 layers over
 // 1 M points 4.75 ms = 231 TF/s fp32-equivalent, against 131 TF/s of the fp32 chain kernel on the same stack.
+//
+// Tried, not kept: the compiler waits for vmcnt(0) -- draining the slab ring -- once per layer for the bias load and once at
+// the first use of an activation block that may come from a load (the input, the addend).  Fetching bias and sign bits one
+// layer ahead with hand-written loads and consuming the tracked loads in front of the ring removed every in-loop vmcnt(0)
+// (asm checked) and changed nothing measurable (config 2: 2.573 -> 2.565 ms per step in this kernel, three A/B pairs on
+// one box): two drains in sixteen slabs are hidden by the second workgroup of the CU.
 #include "npf_common.hpp"
 
 namespace npf {
