@@ -264,17 +264,21 @@ class MergeFlatInputs(nn.Module):
             return self.append_to(ch, x1_pt=x1_pt, x1_modulus=x1_modulus).output_rows().run()[0]
         stack, relus, _ = st
         rl = self.resizer.layers()
+        out = self.flat_module.out
         if x1_pt is not None and x1_modulus == 0 and taskvec is None and mlp_x6.usable(rl):
             # the resizer and the merge on the split kernel as well: x1 enters the resizer's last layer as its addend
             outs = ch.output_pt().run()
             x2 = outs[-1]
             if getattr(ch, "x1_tapped", False):  # (x1 came through the chain: its gradient goes back into that chain's dgrad)
                 x1_pt = outs[0]
-            h = mlp_x6.run_stack(x2, ch.pts, rl + stack, [True] * len(rl) + relus, addend=x1_pt, add_at=len(rl) - 1)
+            tail = out if mlp_x6.tail_usable(out, ch.pts) else None
+            h = mlp_x6.run_stack(x2, ch.pts, rl + stack, [True] * len(rl) + relus, addend=x1_pt, add_at=len(rl) - 1, tail=tail)
         else:
             (h0,) = self._merge_only(ch, x1_pt, x1_modulus, taskvec).output_pt().run()
-            h = mlp_x6.run_stack(h0, ch.pts, stack, relus)
-        out = self.flat_module.out
+            tail = out if mlp_x6.tail_usable(out, ch.pts) else None
+            h = mlp_x6.run_stack(h0, ch.pts, stack, relus, tail=tail)
+        if tail is not None:
+            return h  # (the rows already)
         ch2 = Chain(ch.n_tasks, ch.pts, ch.device)
         ch2.input_pt(h, out.in_features).linear(out.weight, out.bias).output_rows()
         return ch2.run()[0]

@@ -37,6 +37,8 @@ constexpr int kXBiasBytes = 2 * kXF * 4;          // the running and the next la
 struct X6Args {
   npf_x6_layer_t layer[NPF_X6_MAX_LAYERS];
   const float* x;
+  const float* in_rows;  // (x == nullptr) the stack's input = in_w^T in_rows: [points][4] rows through a [4][256] matrix
+  const float* in_w;
   float* y;
   int32_t n_layers;
   int32_t total_tiles;
@@ -82,10 +84,29 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
   // sign-bit tensors: one 64-bit word per lane and half tile, [tile][half][64 lanes]
   const size_t bits_off = ((size_t)(valid ? tile : 0) * 2 + (wave & 1)) * 64 + lane;
   f32x4 cur[16];
-  {
+  if (a.in_rows == nullptr) {
     const float* x = a.x + lane_off;
 #pragma unroll
     for (int b = 0; b < 16; ++b) cur[b] = *(const f32x4*)(x + b * 512);
+  } else {
+    // the dgrad of a 256 -> 4 layer in front of the stack (the decoder's output layer, mlp.py:109): this lane's point has four
+    // dOut values, its 64 features of the gradient = those through W_out [4][256].  W_out waits in the ring's third slot,
+    // which no slab enters before every wave has passed the first stage's barrier.
+    f32x4* wl = (f32x4*)(smem + 2 * kXSlabBytes);
+    wl[tid] = ((const f32x4*)a.in_w)[tid];
+    __syncthreads();
+    const f32x4 dz = ((const f32x4*)a.in_rows)[(size_t)(valid ? tile : 0) * 32 + 16 * (wave & 1) + p];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      f32x4 v = dz[0] * wl[4 * b + g];
+#pragma unroll
+      for (int n = 1; n < 4; ++n) {
+        const f32x4 w = wl[n * 64 + 4 * b + g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(dz[n], w[e], v[e]);
+      }
+      cur[b] = v;
+    }
   }
 
   // DMA of slab s of a layer: 24 pieces of 1 KiB (term q / 8, rows 2 (q % 8), + 1), six per wave; the swizzle (chunk c of
@@ -216,10 +237,11 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
 
 }  // namespace npf
 
-extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, const float* x, float* y, int32_t n_tasks,
-                              int32_t tiles_per_task, void* stream) {
-  if (!layers || n_layers <= 0 || n_layers > NPF_X6_MAX_LAYERS || !x || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
-  if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return NPF_EINVAL;
+static int x6_launch(const npf_x6_layer_t* layers, int32_t n_layers, const float* x, const float* in_rows, const float* in_w,
+                     float* y, int32_t n_tasks, int32_t tiles_per_task, void* stream) {
+  if (!layers || n_layers <= 0 || n_layers > NPF_X6_MAX_LAYERS || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
+  if ((x == nullptr) == (in_rows == nullptr) || (in_rows != nullptr) != (in_w != nullptr)) return NPF_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)in_rows) | ((uintptr_t)in_w)) & 15) return NPF_EINVAL;
   npf::X6Args a;
   for (int l = 0; l < n_layers; ++l) {
     const npf_x6_layer_t& ly = layers[l];
@@ -231,6 +253,8 @@ extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, co
   }
   for (int l = n_layers; l < NPF_X6_MAX_LAYERS; ++l) a.layer[l] = layers[0];
   a.x = x;
+  a.in_rows = in_rows;
+  a.in_w = in_w;
   a.y = y;
   a.n_layers = n_layers;
   a.total_tiles = n_tasks * tiles_per_task;
@@ -238,4 +262,16 @@ extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, co
   hipLaunchKernelGGL(npf::mlp_x6_kernel, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, a);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
+}
+
+extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, const float* x, float* y, int32_t n_tasks,
+                              int32_t tiles_per_task, void* stream) {
+  if (!x) return NPF_EINVAL;
+  return x6_launch(layers, n_layers, x, nullptr, nullptr, y, n_tasks, tiles_per_task, stream);
+}
+
+extern "C" int npf_mlp_x6_run_rows(const npf_x6_layer_t* layers, int32_t n_layers, const float* in_rows, const float* in_w,
+                                   float* y, int32_t n_tasks, int32_t tiles_per_task, void* stream) {
+  if (!in_rows || !in_w) return NPF_EINVAL;
+  return x6_launch(layers, n_layers, nullptr, in_rows, in_w, y, n_tasks, tiles_per_task, stream);
 }

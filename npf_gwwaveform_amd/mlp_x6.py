@@ -34,7 +34,10 @@ def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List
     return [[buf[k, i] for i in range(n)] for k in range(len(kinds))]
 
 
-def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], n_tasks: int, tiles: int) -> None:
+def _launch(layers: Sequence[dict], x: Optional[torch.Tensor], y: Optional[torch.Tensor], n_tasks: int, tiles: int,
+            rows: Optional[torch.Tensor] = None, rows_w: Optional[torch.Tensor] = None) -> None:
+    """``rows`` / ``rows_w`` in place of ``x``: the stack's input is rows [points, 4] through rows_w [4, 256], computed in the
+    kernel's prologue (``npf_mlp_x6_run_rows``)."""
     for i0 in range(0, len(layers), L.NPF_X6_MAX_LAYERS):
         chunk = layers[i0:i0 + L.NPF_X6_MAX_LAYERS]
         last = i0 + L.NPF_X6_MAX_LAYERS >= len(layers)
@@ -49,17 +52,21 @@ def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], 
             arr[j].store_bits = ly["store_bits"].data_ptr() if ly.get("store_bits") is not None else None
             arr[j].mask_bits = ly["mask_bits"].data_ptr() if ly.get("mask_bits") is not None else None
             arr[j].relu = int(bool(ly.get("relu", False)))
-        out = y if last else torch.empty_like(x)
+        out = y if last else torch.empty_like(y)
         if CH.PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        L.check(L.load().npf_mlp_x6_run(arr, len(chunk), L.ptr(x), L.ptr(out), n_tasks, tiles, L.stream_ptr()),
-                "npf_mlp_x6_run")
+        if x is None:
+            L.check(L.load().npf_mlp_x6_run_rows(arr, len(chunk), L.ptr(rows), L.ptr(rows_w), L.ptr(out), n_tasks, tiles,
+                                                 L.stream_ptr()), "npf_mlp_x6_run_rows")
+        else:
+            L.check(L.load().npf_mlp_x6_run(arr, len(chunk), L.ptr(x), L.ptr(out), n_tasks, tiles, L.stream_ptr()),
+                    "npf_mlp_x6_run")
         if CH.PROFILE is not None:
             ev1.record()
             padded = n_tasks * tiles * 32
             nbytes = padded * 32 * sum((ly.get("mask_bits") is not None) + (ly.get("store_bits") is not None) for ly in chunk)
-            nbytes += padded * 1024 * (2 + sum((ly.get("mask") is not None) + (ly.get("store_in") is not None)
+            nbytes += padded * 1024 * ((2 if x is not None else 1) + sum((ly.get("mask") is not None) + (ly.get("store_in") is not None)
                                               + (ly.get("store_out") is not None) + (ly.get("addend") is not None)
                                               for ly in chunk)) + len(chunk) * 3 * 2 * WIDTH * WIDTH
             CH.PROFILE.append(("mlp_x6_kernel", 2 * WIDTH * WIDTH * len(chunk) * n_tasks * tiles * 32, ev0, ev1, nbytes))
@@ -68,12 +75,17 @@ def _launch(layers: Sequence[dict], x: torch.Tensor, y: Optional[torch.Tensor], 
 
 class _MlpX6Fn(torch.autograd.Function):
     """y = stack(x): x, y PT32 [n_tasks, tiles, 64, 32, 4]; ``addend`` (PT32 or None) enters layer ``add_at`` before its
-    ReLU; params = W_0, b_0, W_1, b_1, ... (b may be None)."""
+    ReLU; params = W_0, b_0, W_1, b_1, ... (b may be None).  ``tail``: the last (W, b) pair is a 256 -> 4 layer behind the
+    stack (the decoder's output layer) and the result is its row-major [n_tasks, pts, 4] output: forward through a chain
+    launch, backward inside the stack's dgrad launch (``npf_mlp_x6_run_rows``)."""
 
     @staticmethod
-    def forward(ctx, x, pts, relus, addend, add_at, *params):
+    def forward(ctx, x, pts, relus, addend, add_at, tail, *params):
         n_tasks, tiles = x.shape[0], x.shape[1]
         Ws, bs = list(params[0::2]), list(params[1::2])
+        W_out = b_out = None
+        if tail:
+            W_out, b_out = Ws.pop(), bs.pop()
         train = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
         x = x.detach().contiguous()
         add = addend.detach().contiguous() if addend is not None else None
@@ -96,37 +108,58 @@ class _MlpX6Fn(torch.autograd.Function):
         ctx.n = len(Ws)
         # acts[i] = input of layer i, acts[i + 1] = its output; through save_for_backward: the output y among them would
         # otherwise close a reference cycle (y -> grad_fn -> ctx -> y) that only the cyclic collector frees -- GBs per step
-        ctx.save_for_backward(x, *outs, y, *(both[1] if train else []), *bits)
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
+        ctx.tail = bool(tail)
+        if tail:
+            ch = CH.Chain(n_tasks, pts, x.device)  # (grad mode is off in here: a plain forward launch)
+            ch.input_pt(y, WIDTH).linear(W_out.detach(), b_out.detach() if b_out is not None else None).output_rows()
+            rows = ch.run()[0]
+            ctx.tail_b = b_out is not None
+            ctx.save_for_backward(x, *outs, y, *(both[1] if train else []), *bits, W_out.detach())
+            return rows
+        ctx.save_for_backward(x, *outs, y, *(both[1] if train else []), *bits)
         return y
 
     @staticmethod
     def backward(ctx, g):
         n = ctx.n
         if g is None:
-            return (None,) * (5 + 2 * n)
+            return (None,) * (6 + 2 * n + 2 * ctx.tail)
         saved = list(ctx.saved_tensors)
+        W_out = saved.pop() if ctx.tail else None
         acts, imgs_t, bits = saved[:n + 1], saved[n + 1:2 * n + 1], saved[2 * n + 1:]
         bit_of = dict(zip([i for i in range(n) if ctx.relus[i]], bits))
         n_tasks, tiles = ctx.geom
         g = g.contiguous()
-        dzs = [torch.empty_like(g) for _ in range(n)]
+        dzs = [torch.empty_like(acts[0]) for _ in range(n)]
         layers = []
         for i in range(n - 1, -1, -1):  # dZ_i = g_i masked by the layer's own output; g_{i-1} = W_i^T dZ_i
             layers.append(dict(img=imgs_t[i], mask_bits=bit_of.get(i), store_in=dzs[i]))
-        dx = torch.empty_like(g)
-        _launch(layers, g, dx, n_tasks, tiles)
+        dx = torch.empty_like(acts[0])
+        if ctx.tail:  # g = dOut rows [n_tasks, pts, 4] (pts a multiple of 32): W_out^T dOut is formed inside the launch
+            _launch(layers, None, dx, n_tasks, tiles, rows=g, rows_w=W_out)
+        else:
+            _launch(layers, g, dx, n_tasks, tiles)
         jobs, grads = [], []
         for i in range(n):
             dW = torch.empty((WIDTH, WIDTH), dtype=torch.float32, device=g.device)
             db = torch.empty((WIDTH,), dtype=torch.float32, device=g.device) if ctx.has_b[i] else None
             jobs.append(dict(dZ=dzs[i], A=acts[i], N=WIDTH, K=WIDTH, dW=dW, db=db))
             grads += [dW, db]
+        if ctx.tail:
+            # the output layer's weight gradient: its dZ = dOut as a PT32 tensor (4 of a tile's 32 feature slots; the rows of
+            # a tile are exactly the tile's first feature group)
+            dz_out = torch.zeros(CH.pt_shape(n_tasks, ctx.pts, 4), dtype=torch.float32, device=g.device)
+            dz_out[:, :, 0] = g.view(n_tasks, tiles, 32, 4)
+            dW = torch.empty((4, WIDTH), dtype=torch.float32, device=g.device)
+            db = torch.empty((4,), dtype=torch.float32, device=g.device) if ctx.tail_b else None
+            jobs.append(dict(dZ=dz_out, A=acts[n], N=4, K=WIDTH, dW=dW, db=db))
+            grads += [dW, db]
         CH.run_wgrad(jobs, n_tasks, ctx.pts, g.device)
         # the addend's gradient is the dZ of its layer (it enters in front of the ReLU, with unit weight)
         d_add = dzs[ctx.add_at] if ctx.add_at >= 0 else None
-        return (dx, None, None, d_add, None, *grads)
+        return (dx, None, None, d_add, None, None, *grads)
 
 
 def usable(linears: Sequence[torch.nn.Linear]) -> bool:
@@ -135,11 +168,20 @@ def usable(linears: Sequence[torch.nn.Linear]) -> bool:
             and all(l.in_features == WIDTH and l.out_features == WIDTH for l in linears))
 
 
+# The decoder's 256 -> 4 output layer rides on the stack (NPF_NO_X6_TAIL=1: a chain of its own, forward and backward).
+TAIL = os.environ.get("NPF_NO_X6_TAIL", "0") != "1"
+
+
+def tail_usable(out: torch.nn.Linear, pts: int) -> bool:
+    return TAIL and out.in_features == WIDTH and out.out_features == 4 and pts % 32 == 0
+
+
 def run_stack(x_pt: torch.Tensor, pts: int, linears: Sequence[torch.nn.Linear], relus: Sequence[bool],
-              addend: Optional[torch.Tensor] = None, add_at: int = 0) -> torch.Tensor:
+              addend: Optional[torch.Tensor] = None, add_at: int = 0, tail: Optional[torch.nn.Linear] = None) -> torch.Tensor:
     """PT32 [n_tasks, tiles, 64, 32, 4] -> the same shape through ``linears`` (256 -> 256 each), ReLU behind layer i when
-    ``relus[i]``; ``addend`` (PT32, same shape) is added in front of the ReLU of layer ``add_at``."""
+    ``relus[i]``; ``addend`` (PT32, same shape) is added in front of the ReLU of layer ``add_at``.  With ``tail`` (a
+    256 -> 4 Linear, ``tail_usable``): the row-major [n_tasks, pts, 4] output of that layer behind the stack."""
     params = []
-    for lin in linears:
+    for lin in list(linears) + ([tail] if tail is not None else []):
         params += [lin.weight, lin.bias]
-    return _MlpX6Fn.apply(x_pt, pts, tuple(bool(r) for r in relus), addend, int(add_at), *params)
+    return _MlpX6Fn.apply(x_pt, pts, tuple(bool(r) for r in relus), addend, int(add_at), tail is not None, *params)

@@ -453,6 +453,50 @@ def test_mlp_x6_stack_forward_and_backward_match_float64():
             assert_close(a.bias.grad, b.bias.grad, tol=1e-4, what=f"x6 stack db[{i}]")
 
 
+def test_mlp_x6_stack_with_output_layer_rows_matches_float64():
+    """The decoder's 256 -> 4 output layer riding on the stack (``run_stack(tail=...)``): rows forward through a chain launch,
+    its dgrad formed inside the stack's dgrad launch (npf_mlp_x6_run_rows), its dW / db from the rows as a PT32 operand --
+    rows, dx, d(addend) and every dW / db against float64, at the tolerances of the fp32 kernels; odd tile counts, more
+    layers than one launch takes."""
+    from npf_gwwaveform_amd import mlp_x6
+
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(59)
+    for n_tasks, pts, n_layers, add_at in ((3, 32, 2, -1), (1, 96, 6, 1), (2, 64, 10, -1)):
+        lins = [torch.nn.Linear(256, 256) for _ in range(n_layers)] + [torch.nn.Linear(256, 4)]
+        for lin in lins:
+            lin.weight.data = torch.randn(lin.weight.shape, generator=g) * 0.09
+            lin.bias.data = torch.randn(lin.bias.shape, generator=g) * 0.1
+        assert mlp_x6.tail_usable(lins[-1], pts) and not mlp_x6.tail_usable(lins[-1], pts + 1)
+        x = torch.randn(n_tasks, pts, 256, generator=g)
+        w = torch.randn(n_tasks, pts, 4, generator=g)
+        addend = torch.randn(n_tasks, pts, 256, generator=g) if add_at >= 0 else None
+        ref_lins = [torch.nn.Linear(l.in_features, l.out_features).double() for l in lins]
+        for a, b in zip(ref_lins, lins):
+            a.load_state_dict({k: v.double() for k, v in b.state_dict().items()})
+        xr = x.double().requires_grad_(True)
+        ar = addend.double().requires_grad_(True) if addend is not None else None
+        h = xr
+        for i, lin in enumerate(ref_lins[:-1]):
+            h = torch.relu(lin(h) + (ar if i == add_at else 0.0))
+        rows_ref = ref_lins[-1](h)
+        (rows_ref * w.double()).sum().backward()
+        dev_lins = [lin.to(DEV) for lin in lins]
+        xd = x.to(DEV).requires_grad_(True)
+        ad = addend.to(DEV).requires_grad_(True) if addend is not None else None
+        rows = mlp_x6.run_stack(FN.pack_pt(xd), pts, dev_lins[:-1], [True] * n_layers,
+                                addend=FN.pack_pt(ad) if ad is not None else None, add_at=max(add_at, 0), tail=dev_lins[-1])
+        assert tuple(rows.shape) == (n_tasks, pts, 4)
+        (rows * w.to(DEV)).sum().backward()
+        assert_close(rows, rows_ref, tol=1e-5, what=f"x6 stack + output rows ({n_layers} layers)")
+        assert_close(xd.grad, xr.grad, tol=1e-4, what="x6 stack + rows dx")
+        if ad is not None:
+            assert_close(ad.grad, ar.grad, tol=1e-4, what="x6 stack + rows d(addend)")
+        for i, (a, b) in enumerate(zip(dev_lins, ref_lins)):
+            assert_close(a.weight.grad, b.weight.grad, tol=1e-4, what=f"x6 stack + rows dW[{i}]")
+            assert_close(a.bias.grad, b.bias.grad, tol=1e-4, what=f"x6 stack + rows db[{i}]")
+
+
 def _pack_pt16_reference(x):
     """Row-major [B, P, F] -> PT16 (bf16 tiles) with plain torch ops (the layout of chain.pt16_shape)."""
     B, P, F = x.shape
