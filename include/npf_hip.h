@@ -319,12 +319,16 @@ typedef struct {
 } npf_x6_layer_t;
 int npf_mlp_x6_run(const npf_x6_layer_t *layers, int32_t n_layers, const float *x, float *y, int32_t n_tasks,
                    int32_t tiles_per_task, void *stream);
-/* The same with the stack's input computed in place of read: x[point][f] = sum_n in_rows[point][n] in_w[n][f], in_rows
- * [n_tasks * tiles_per_task * 32][4] row-major, in_w [4][256] fp32 -- the dgrad of a 256 -> 4 layer in front of the dgrad of the
- * stack (the decoder's output layer, npf/architectures/mlp.py:109, whose gradient dOut the Gaussian head's backward leaves as
- * rows): the 256-wide gradient is never written to or read from HBM.  Plain fp32 FMAs (four terms per value). */
-int npf_mlp_x6_run_rows(const npf_x6_layer_t *layers, int32_t n_layers, const float *in_rows, const float *in_w, float *y,
-                        int32_t n_tasks, int32_t tiles_per_task, void *stream);
+/* The same with a 256 -> 4 layer on either side of the stack (the decoder's output layer, npf/architectures/mlp.py:109), as rows
+ * [n_tasks * tiles_per_task * 32][4] row-major and a [4][256] fp32 matrix, in plain fp32 FMAs:
+ *  - in front (x == NULL): x[point][f] = sum_n in_rows[point][n] in_w[n][f] -- the dgrad of that layer ahead of the dgrad of
+ *    the stack (in_rows = dOut as the Gaussian head's backward leaves it, in_w = W_out): the 256-wide gradient is never
+ *    written to or read from HBM;
+ *  - behind (out_rows != NULL): out_rows[point][n] = sum_f out_w[n][f] cur[f] + out_b[n] from the registers the last layer
+ *    leaves (forward; y may be NULL when the stack's own output is not needed). */
+int npf_mlp_x6_run_rows(const npf_x6_layer_t *layers, int32_t n_layers, const float *x, const float *in_rows, const float *in_w,
+                        float *y, const float *out_w, const float *out_b, float *out_rows, int32_t n_tasks,
+                        int32_t tiles_per_task, void *stream);
 
 int npf_version(void);
 

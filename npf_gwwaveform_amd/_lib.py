@@ -95,7 +95,7 @@ SIGNATURES = {
     "npf_split_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_merge_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_mlp_x6_run": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _i32, _i32, _p]),
-    "npf_mlp_x6_run_rows": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _p, _i32, _i32, _p]),
+    "npf_mlp_x6_run_rows": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
     "npf_version": (C.c_int, []),
 }
 

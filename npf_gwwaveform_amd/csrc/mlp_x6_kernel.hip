@@ -40,6 +40,9 @@ struct X6Args {
   const float* in_rows;  // (x == nullptr) the stack's input = in_w^T in_rows: [points][4] rows through a [4][256] matrix
   const float* in_w;
   float* y;
+  const float* out_w;  // (out_rows != nullptr) a 256 -> 4 layer behind the stack: out_rows [points][4] = out_w [4][256] cur + out_b
+  const float* out_b;
+  float* out_rows;
   int32_t n_layers;
   int32_t total_tiles;
 };
@@ -233,15 +236,44 @@ __global__ __launch_bounds__(256, 2) void mlp_x6_kernel(const X6Args a) {
 #pragma unroll
     for (int b = 0; b < 16; ++b) *(f32x4*)(y + b * 512) = cur[b];
   }
+  if (a.out_rows != nullptr) {
+    // the decoder's output layer (mlp.py:109) on the registers the stack leaves: a lane holds 64 of its point's 256 features,
+    // four fp32 dot products over them, summed over the point's four lanes.  W_out goes where the ring was.
+    __syncthreads();  // (every wave is done with the last slabs)
+    f32x4* wl = (f32x4*)smem;
+    wl[tid] = ((const f32x4*)a.out_w)[tid];
+    __syncthreads();
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 w = wl[n * 64 + 4 * b + g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[n] = fmaf(w[e], cur[b][e], r[n]);
+      }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      r[n] += __shfl_xor(r[n], 16);
+      r[n] += __shfl_xor(r[n], 32);
+      if (a.out_b != nullptr) r[n] += a.out_b[n];
+    }
+    if (valid && g == 0) ((f32x4*)a.out_rows)[(size_t)tile * 32 + 16 * (wave & 1) + p] = r;
+  }
 }
 
 }  // namespace npf
 
-static int x6_launch(const npf_x6_layer_t* layers, int32_t n_layers, const float* x, const float* in_rows, const float* in_w,
-                     float* y, int32_t n_tasks, int32_t tiles_per_task, void* stream) {
+extern "C" int npf_mlp_x6_run_rows(const npf_x6_layer_t* layers, int32_t n_layers, const float* x, const float* in_rows,
+                                   const float* in_w, float* y, const float* out_w, const float* out_b, float* out_rows,
+                                   int32_t n_tasks, int32_t tiles_per_task, void* stream) {
   if (!layers || n_layers <= 0 || n_layers > NPF_X6_MAX_LAYERS || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
   if ((x == nullptr) == (in_rows == nullptr) || (in_rows != nullptr) != (in_w != nullptr)) return NPF_EINVAL;
-  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)in_rows) | ((uintptr_t)in_w)) & 15) return NPF_EINVAL;
+  if ((out_rows != nullptr) != (out_w != nullptr) || (out_b != nullptr && out_rows == nullptr)) return NPF_EINVAL;
+  if (y == nullptr && out_rows == nullptr) return NPF_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)in_rows) | ((uintptr_t)in_w) | ((uintptr_t)out_w) | ((uintptr_t)out_rows)) & 15)
+    return NPF_EINVAL;
+  if (((uintptr_t)out_b) & 3) return NPF_EINVAL;
   npf::X6Args a;
   for (int l = 0; l < n_layers; ++l) {
     const npf_x6_layer_t& ly = layers[l];
@@ -256,6 +288,9 @@ static int x6_launch(const npf_x6_layer_t* layers, int32_t n_layers, const float
   a.in_rows = in_rows;
   a.in_w = in_w;
   a.y = y;
+  a.out_w = out_w;
+  a.out_b = out_b;
+  a.out_rows = out_rows;
   a.n_layers = n_layers;
   a.total_tiles = n_tasks * tiles_per_task;
   const int n_wg = (a.total_tiles + 1) / 2;
@@ -266,12 +301,6 @@ static int x6_launch(const npf_x6_layer_t* layers, int32_t n_layers, const float
 
 extern "C" int npf_mlp_x6_run(const npf_x6_layer_t* layers, int32_t n_layers, const float* x, float* y, int32_t n_tasks,
                               int32_t tiles_per_task, void* stream) {
-  if (!x) return NPF_EINVAL;
-  return x6_launch(layers, n_layers, x, nullptr, nullptr, y, n_tasks, tiles_per_task, stream);
-}
-
-extern "C" int npf_mlp_x6_run_rows(const npf_x6_layer_t* layers, int32_t n_layers, const float* in_rows, const float* in_w,
-                                   float* y, int32_t n_tasks, int32_t tiles_per_task, void* stream) {
-  if (!in_rows || !in_w) return NPF_EINVAL;
-  return x6_launch(layers, n_layers, nullptr, in_rows, in_w, y, n_tasks, tiles_per_task, stream);
+  if (!x || !y) return NPF_EINVAL;
+  return npf_mlp_x6_run_rows(layers, n_layers, x, nullptr, nullptr, y, nullptr, nullptr, nullptr, n_tasks, tiles_per_task, stream);
 }

@@ -35,9 +35,11 @@ def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List
 
 
 def _launch(layers: Sequence[dict], x: Optional[torch.Tensor], y: Optional[torch.Tensor], n_tasks: int, tiles: int,
-            rows: Optional[torch.Tensor] = None, rows_w: Optional[torch.Tensor] = None) -> None:
+            rows: Optional[torch.Tensor] = None, rows_w: Optional[torch.Tensor] = None,
+            out: Optional[tuple] = None) -> None:
     """``rows`` / ``rows_w`` in place of ``x``: the stack's input is rows [points, 4] through rows_w [4, 256], computed in the
-    kernel's prologue (``npf_mlp_x6_run_rows``)."""
+    kernel's prologue; ``out`` = (W [4, 256], b [4] or None, rows [points, 4]): a 256 -> 4 layer on the registers the last
+    layer leaves (``npf_mlp_x6_run_rows``)."""
     for i0 in range(0, len(layers), L.NPF_X6_MAX_LAYERS):
         chunk = layers[i0:i0 + L.NPF_X6_MAX_LAYERS]
         last = i0 + L.NPF_X6_MAX_LAYERS >= len(layers)
@@ -52,15 +54,19 @@ def _launch(layers: Sequence[dict], x: Optional[torch.Tensor], y: Optional[torch
             arr[j].store_bits = ly["store_bits"].data_ptr() if ly.get("store_bits") is not None else None
             arr[j].mask_bits = ly["mask_bits"].data_ptr() if ly.get("mask_bits") is not None else None
             arr[j].relu = int(bool(ly.get("relu", False)))
-        out = y if last else torch.empty_like(y)
+        tail = out if (last and out is not None) else None
+        out_t = y if last else torch.empty_like(y)
         if CH.PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if x is None:
-            L.check(L.load().npf_mlp_x6_run_rows(arr, len(chunk), L.ptr(rows), L.ptr(rows_w), L.ptr(out), n_tasks, tiles,
-                                                 L.stream_ptr()), "npf_mlp_x6_run_rows")
+        if x is None or tail is not None:
+            L.check(L.load().npf_mlp_x6_run_rows(
+                arr, len(chunk), L.ptr(x) if x is not None else None, L.ptr(rows) if x is None else None,
+                L.ptr(rows_w) if x is None else None, L.ptr(out_t), L.ptr(tail[0]) if tail else None,
+                L.ptr(tail[1]) if (tail and tail[1] is not None) else None, L.ptr(tail[2]) if tail else None,
+                n_tasks, tiles, L.stream_ptr()), "npf_mlp_x6_run_rows")
         else:
-            L.check(L.load().npf_mlp_x6_run(arr, len(chunk), L.ptr(x), L.ptr(out), n_tasks, tiles, L.stream_ptr()),
+            L.check(L.load().npf_mlp_x6_run(arr, len(chunk), L.ptr(x), L.ptr(out_t), n_tasks, tiles, L.stream_ptr()),
                     "npf_mlp_x6_run")
         if CH.PROFILE is not None:
             ev1.record()
@@ -70,14 +76,14 @@ def _launch(layers: Sequence[dict], x: Optional[torch.Tensor], y: Optional[torch
                                               + (ly.get("store_out") is not None) + (ly.get("addend") is not None)
                                               for ly in chunk)) + len(chunk) * 3 * 2 * WIDTH * WIDTH
             CH.PROFILE.append(("mlp_x6_kernel", 2 * WIDTH * WIDTH * len(chunk) * n_tasks * tiles * 32, ev0, ev1, nbytes))
-        x = out
+        x = out_t
 
 
 class _MlpX6Fn(torch.autograd.Function):
     """y = stack(x): x, y PT32 [n_tasks, tiles, 64, 32, 4]; ``addend`` (PT32 or None) enters layer ``add_at`` before its
     ReLU; params = W_0, b_0, W_1, b_1, ... (b may be None).  ``tail``: the last (W, b) pair is a 256 -> 4 layer behind the
-    stack (the decoder's output layer) and the result is its row-major [n_tasks, pts, 4] output: forward through a chain
-    launch, backward inside the stack's dgrad launch (``npf_mlp_x6_run_rows``)."""
+    stack (the decoder's output layer) and the result is its row-major [n_tasks, pts, 4] output: forward on the registers the
+    last layer leaves, backward in the prologue of the stack's dgrad launch (``npf_mlp_x6_run_rows``)."""
 
     @staticmethod
     def forward(ctx, x, pts, relus, addend, add_at, tail, *params):
@@ -103,7 +109,13 @@ class _MlpX6Fn(torch.autograd.Function):
                 ly["store_bits"] = torch.empty((n_tasks, tiles, 2, 64), dtype=torch.int64, device=x.device)
                 bits.append(ly["store_bits"])
             layers.append(ly)
-        _launch(layers, x, y, n_tasks, tiles)
+        rows = None
+        if tail:  # the output layer on the registers the last layer leaves: [n_tasks, pts, 4] (pts a multiple of 32)
+            rows = torch.empty((n_tasks, pts, 4), dtype=torch.float32, device=x.device)
+            _launch(layers, x, y, n_tasks, tiles,
+                    out=(W_out.detach().contiguous(), b_out.detach() if b_out is not None else None, rows))
+        else:
+            _launch(layers, x, y, n_tasks, tiles)
         ctx.pts, ctx.relus, ctx.geom, ctx.add_at = pts, tuple(relus), (n_tasks, tiles), (add_at if addend is not None else -1)
         ctx.n = len(Ws)
         # acts[i] = input of layer i, acts[i + 1] = its output; through save_for_backward: the output y among them would
@@ -112,9 +124,6 @@ class _MlpX6Fn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.tail = bool(tail)
         if tail:
-            ch = CH.Chain(n_tasks, pts, x.device)  # (grad mode is off in here: a plain forward launch)
-            ch.input_pt(y, WIDTH).linear(W_out.detach(), b_out.detach() if b_out is not None else None).output_rows()
-            rows = ch.run()[0]
             ctx.tail_b = b_out is not None
             ctx.save_for_backward(x, *outs, y, *(both[1] if train else []), *bits, W_out.detach())
             return rows

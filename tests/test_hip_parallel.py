@@ -66,8 +66,18 @@ def test_two_rank_trainer_equals_global_batch_step(name, tmp_path):
         assert abs(mean_loss - ref_losses[s]) <= 2e-6 * abs(ref_losses[s]), (s, mean_loss, ref_losses[s])
         g, want = res[0]["grads"][s].double(), ref_grads[s].double()
         assert (g - want).abs().max() <= 1e-6 * want.abs().max(), (s, float((g - want).abs().max()), float(want.abs().max()))
-    # post-Adam weights after the steps: 1e-5 absolute = 1 % of lr = 1e-3 (weights O(0.1)).  Adam divides by sqrt(v): where
-    # a gradient entry is ~1e-3 of the tensor's largest, the 1e-6-of-max summation-order difference above is 1e-3 of the
-    # entry itself and moves that weight's step by 1e-3 lr; the largest such entry seen is 4e-6
+    # post-Adam weights after the steps.  Adam divides by sqrt(v): its step is lr * sign-like in the gradient, so the
+    # 1e-6-of-max summation-order difference asserted above moves a weight by (difference / |entry|) * lr.  Entries whose
+    # gradient is >= 1e-3 of the largest in every step (difference <= 1e-3 of the entry) must agree to 1e-5 = 1 % of lr;
+    # entries down to 1e-4 of the largest (difference <= 1e-2 of the entry) to 1e-4; below that the same noise is a large
+    # fraction of the entry itself, up to its sign: Adam's own bound of about a step per step, and no more than 1e-4 of
+    # all weights may be beyond 1e-5 at all
+    lr, steps = 1e-3, len(ref_grads)
     d = (res[0]["weights"].double() - ref_w.double()).abs()
-    assert d.max() <= 1e-5, float(d.max())
+    gmin = torch.stack([g.double().abs() for g in ref_grads]).min(0).values
+    gmax = max(float(g.abs().max()) for g in ref_grads)
+    big, mid = gmin >= 1e-3 * gmax, gmin >= 1e-4 * gmax
+    assert d[big].max() <= 1e-5, float(d[big].max())
+    assert d[mid].max() <= 1e-4, float(d[mid].max())
+    assert d.max() <= 2.5 * lr * steps, float(d.max())
+    assert float((d > 1e-5).double().mean()) <= 1e-4, float((d > 1e-5).double().mean())
