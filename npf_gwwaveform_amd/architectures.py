@@ -91,7 +91,12 @@ class MLP(nn.Module):
         (mlp.py:100-104)."""
         ls = self.layers()
         for j, lin in enumerate(ls):
-            if (j == 0 and skip_first) or (j == len(ls) - 1 and skip_last):
+            if j == len(ls) - 1 and skip_last:
+                continue
+            if j == 0 and skip_first:
+                # (the caller ran ``to_hidden`` + ReLU itself; the dropout behind it, mlp.py:96-98, is still this module's)
+                if len(ls) > 1 and self.dropout_p > 0 and self.training:
+                    ch.dropout(self._sign_mask(ch, lin.out_features), self.dropout_p)
                 continue
             W = lin.weight
             if j == 0 and W.shape[1] % 4 != 0 and W.shape[1] == ch.F:

@@ -58,7 +58,10 @@ __device__ __forceinline__ unsigned x6m_cvt_pk(float a, float b) {
   return r;
 }
 
-// the 8 values of a lane's two adjacent blocks (the B operand of one 32-feature k-step) as three packed bf16 terms
+// the 8 values of a lane's two adjacent blocks (the B operand of one 32-feature k-step) as three packed bf16 terms.
+// Edge values (tests/test_hip_kernels.py::test_mlp_x6_split_edge_values): exact for every finite |x| <= 3.3895e38 (the largest
+// bf16), subnormals included; a non-finite x gives non-finite terms (inf - inf), i.e. a non-finite output like fp32 arithmetic;
+// a finite |x| above the largest bf16 (the last 0.4 % of the fp32 range) rounds to infinity in the first term: non-finite too.
 __device__ __forceinline__ void x6m_split(const f32x4& lo, const f32x4& hi, x6_u32x4& t0, x6_u32x4& t1, x6_u32x4& t2) {
   const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll

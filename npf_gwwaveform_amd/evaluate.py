@@ -2,6 +2,7 @@
 its skorch harness: seed, evaluation mode, per-task (``reduction=None``) log-likelihoods of every batch in order."""
 from __future__ import annotations
 
+import random
 from typing import Iterable
 
 import numpy as np
@@ -18,7 +19,12 @@ def eval_loglike(model: torch.nn.Module, criterion: torch.nn.Module, batches: It
     lazily -- the same context / target draws on every call), model and criterion run in evaluation mode (so the
     criterion is the log-mean-exp over ``n_z_samples_test`` latent samples), the criterion's reduction is switched
     off for the call and restored afterwards, and the sign is flipped (log-likelihood, not loss)."""
+    # utils/helpers.py:49-55 (set_seed): torch (+ cuda), random, numpy -- GetRandomIndcs draws the context size with
+    # Python's ``random`` (npf/utils/datasplit.py:68,74)
     torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    random.seed(seed)
     np.random.seed(seed)
     was_training = (model.training, criterion.training)
     old_reduction = criterion.reduction

@@ -125,7 +125,9 @@ class Trainer:
             self.model.validate_inputs = "deferred" if was else False
             # (the running maximum lives outside the graph's memory pool: a tensor created during capture would be
             # re-initialised by every replay)
-            self.model._range_seen = torch.zeros((), device=self.flat.flat.device)
+            seen = getattr(self.model, "_range_seen", None)
+            if seen is None or seen.device != self.flat.flat.device:  # (kept across re-captures: a verdict not yet read survives)
+                self.model._range_seen = torch.zeros((), device=self.flat.flat.device)
             try:
                 self._static = {k: v.clone() for k, v in batch.items()}
                 torch.cuda.synchronize()
@@ -192,8 +194,18 @@ class Trainer:
             raise ValueError("optimizer state with several parameter groups")
         ids = list(groups[0]["params"])
         dev = self.flat.flat.device
+        # a captured step holds the ADDRESSES of the moment / step tensors: whatever is loaded is copied into the existing
+        # tensors, and the graph is dropped anyway (the next step re-captures after its eager warm-up)
+        self._graph, self._eager_steps = None, 0
         if len(ids) == 1 and len(self.flat.params) != 1:  # the flat layout (one parameter = the whole buffer)
+            old = dict(self.opt.state.get(self.flat.flat) or {})
             self.opt.load_state_dict(sd)
+            st = self.opt.state.get(self.flat.flat)
+            if st and old:
+                for key in ("exp_avg", "exp_avg_sq", "step"):
+                    if torch.is_tensor(old.get(key)) and torch.is_tensor(st.get(key)) and old[key].shape == st[key].shape:
+                        old[key].copy_(st[key].to(old[key].device, old[key].dtype))
+                        st[key] = old[key]
         else:
             if len(ids) != len(self.flat.params):
                 raise ValueError(f"optimizer state for {len(ids)} parameters, the model has {len(self.flat.params)}")
@@ -216,8 +228,15 @@ class Trainer:
                 st = self.opt.state[self.flat.flat]
                 like = st.get("step")
                 step = torch.tensor(steps.pop(), dtype=torch.float32)
-                st["step"] = step.to(like.device) if torch.is_tensor(like) else (step.to(dev) if self.flat.flat.is_cuda else step)
-                st["exp_avg"], st["exp_avg_sq"] = exp_avg, exp_avg_sq
+                if torch.is_tensor(like):
+                    like.copy_(step.to(like.device, like.dtype))
+                else:
+                    st["step"] = step.to(dev) if self.flat.flat.is_cuda else step
+                for key, new in (("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+                    if torch.is_tensor(st.get(key)) and st[key].shape == new.shape:
+                        st[key].copy_(new)
+                    else:
+                        st[key] = new
 
     def save_checkpoint(self, dirname: str, history: Optional[list] = None) -> None:
         """skorch ``Checkpoint`` layout, interchangeable with the reference's: ``params.pt`` = the module's state_dict
@@ -233,6 +252,7 @@ class Trainer:
         (e.g. ``results/pretrained/*/run_0/``).  Loaded with ``weights_only=True``."""
         sd = torch.load(os.path.join(dirname, "params.pt"), map_location="cpu", weights_only=True)
         self.model.load_state_dict(sd, strict=True)  # parameters are views of the flat buffer: copied in place
+        self._graph, self._eager_steps = None, 0     # (a captured step is re-captured after the load)
         opt_path = os.path.join(dirname, "optimizer.pt")
         if load_optimizer and os.path.exists(opt_path):
             try:

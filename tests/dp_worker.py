@@ -46,7 +46,10 @@ def main():
         losses.append(float(trainer.step(local).item()))
         grads.append(trainer.flat.flat_grad.detach().cpu().clone())
     torch.cuda.synchronize()
-    torch.save({"rank": rank, "losses": losses, "grads": grads, "weights": trainer.flat.flat.detach().cpu().clone()}, out_path)
+    st = trainer.opt.state[trainer.flat.flat]
+    torch.save({"rank": rank, "losses": losses, "grads": grads, "weights": trainer.flat.flat.detach().cpu().clone(),
+                "exp_avg": st["exp_avg"].detach().cpu().clone(), "exp_avg_sq": st["exp_avg_sq"].detach().cpu().clone(),
+                "step": float(st["step"])}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -85,6 +85,10 @@ VARIANT_CASES = {
     # dropout in the XY-encoder / decoder MLPs (mlp.py:81,98,105): the masks the reference drew are stored (dropmask/i)
     "g14_cnp_drop": dict(kind="CNP", r=32, L_xy=2, L_dec=3, dx=1, dy=2, B=3, C=9, T=40, dropout=0.25),
     "g14_attncnp_drop_res": dict(kind="AttnCNP", r=64, L_xy=3, L_dec=3, dx=1, dy=2, B=2, C=20, T=45, dropout=0.4, is_res=True),
+    # concatenating merge WITH dropout: the first dropout sits behind the layer that runs as two accumulating halves
+    "g14_cnp_cat_drop": dict(kind="CNP", r=32, L_xy=2, L_dec=2, dx=1, dy=2, B=3, C=9, T=40, is_sum_merge=False, dropout=0.3),
+    "g14_attncnp_cat_drop": dict(kind="AttnCNP", r=64, L_xy=3, L_dec=2, dx=1, dy=2, B=2, C=20, T=45, is_sum_merge=False,
+                                 dropout=0.2, is_res=True),
     "g14_attnlnp_all": dict(kind="AttnLNP", r=64, L_xy=3, L_dec=3, dx=1, dy=2, B=2, C=20, T=45, is_q_zCct=True, n_z=2,
                             is_sum_merge=False, is_res=True, x_transf_dim=32),
 }

@@ -453,6 +453,43 @@ def test_mlp_x6_stack_forward_and_backward_match_float64():
             assert_close(a.bias.grad, b.bias.grad, tol=1e-4, what=f"x6 stack db[{i}]")
 
 
+def test_mlp_x6_split_edge_values():
+    """Edge semantics of the three-term split (csrc/mlp_x6_kernel.hip, x6m_split) against fp32 ``F.linear``:
+    (1) huge finite inputs up to 3.38e38 (just under the largest bf16, 3.3895e38): exact like any other value;
+    (2) subnormal-range and zero inputs: exact;
+    (3) a non-finite input (inf / nan) makes that point's outputs non-finite, as the reference's fp32 addmm does (inf * w, and
+        inf - inf = nan across mixed signs), and leaves every other point untouched;
+    (4) DOCUMENTED DEVIATION: a finite input in (3.3895e38, FLT_MAX] rounds to bf16 infinity in the first term, so its point
+        comes out non-finite where fp32 arithmetic would still be finite -- the last 0.4 % of the fp32 range, where the
+        reference's own next layer overflows."""
+    from npf_gwwaveform_amd import mlp_x6
+
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(61)
+    lin = torch.nn.Linear(256, 256)
+    lin.weight.data = torch.randn(256, 256, generator=g) * 1e-3  # (products and sums stay finite)
+    lin.bias.data.zero_()
+    pts = 64
+    x = torch.randn(1, pts, 256, generator=g)
+    x[0, 1, :] = torch.where(torch.rand(256, generator=g) < 0.5, 3.38e38, -3.38e38)   # (1)
+    x[0, 2, ::2] = 1e-39                                                               # (2) subnormal
+    x[0, 2, 1::2] = 0.0
+    x[0, 3, 7] = float("inf")                                                          # (3)
+    x[0, 4, 9] = float("nan")
+    x[0, 5, 11] = 3.40e38                                                              # (4)
+    with torch.no_grad():
+        ref64 = torch.nn.functional.linear(x.double(), lin.weight.double())
+        y = FN.unpack_pt(mlp_x6.run_stack(FN.pack_pt(x.to(DEV)), pts, [lin.to(DEV)], [False]), pts, 256).cpu()
+    finite_pts = [p for p in range(pts) if p not in (3, 4, 5)]
+    assert torch.isfinite(y[0, finite_pts]).all()
+    for p in (0, 1, 2, 6):
+        m = (x[0, p].double().abs() @ lin.weight.double().abs().T).max()
+        assert float((y[0, p].double() - ref64[0, p]).abs().max()) <= 1e-6 * float(m), p
+    for p in (3, 4, 5):
+        assert not torch.isfinite(y[0, p]).any(), p
+    assert torch.isfinite(torch.nn.functional.linear(x[0, 5], lin.weight.cpu())).all()  # (fp32 itself is still finite there)
+
+
 def test_mlp_x6_stack_with_output_layer_rows_matches_float64():
     """The decoder's 256 -> 4 output layer riding on the stack (``run_stack(tail=...)``): rows forward through a chain launch,
     its dgrad formed inside the stack's dgrad launch (npf_mlp_x6_run_rows), its dW / db from the rows as a PT32 operand --

@@ -115,3 +115,33 @@ def test_eval_loglike_matches_the_reference_protocol():
         assert ll.shape == g[f"{tag}_loglike"].shape
         np.testing.assert_allclose(ll, g[f"{tag}_loglike"], rtol=2e-5, err_msg=tag)
         assert crit.reduction == "mean" and model.training and crit.training
+
+
+def test_eval_loglike_reseeds_lazily_drawn_batches():
+    """utils/evaluate.py:9-28 seeds before iterating: batches drawn lazily through ``CntxtTrgtGetter(GetRandomIndcs)`` --
+    context size from Python's ``random`` (datasplit.py:68,74), subsets from the device generator -- are the same draws on
+    every call, so two calls return the same per-task log-likelihoods."""
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd.datasplit import CntxtTrgtGetter, GetRandomIndcs, get_all_indcs
+
+    case = specs.EVAL_CASES["cnp"]
+    model = build_model(case, DEV).eval()
+    crit = A.CNPFLoss()
+    getter = CntxtTrgtGetter(contexts_getter=GetRandomIndcs(a=3, b=20), targets_getter=get_all_indcs)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    X = (torch.rand(4, 40, case["dx"], generator=g) * 2 - 1).to(DEV)
+    Y = torch.randn(4, 40, case["dy"], generator=g).to(DEV)
+    sizes = []
+
+    def batches():
+        for _ in range(3):
+            Xc, Yc, Xt, Yt = getter(X, Y)
+            sizes.append(Xc.shape[1])
+            yield dict(X_cntxt=Xc, Y_cntxt=Yc, X_trgt=Xt, Y_trgt=Yt)
+
+    a = A.eval_loglike(model, crit, batches(), seed=123)
+    b = A.eval_loglike(model, crit, batches(), seed=123)
+    assert sizes[:3] == sizes[3:] and len(set(sizes[:3])) > 1, sizes
+    np.testing.assert_array_equal(a, b)
+    c = A.eval_loglike(model, crit, batches(), seed=124)
+    assert not np.array_equal(a, c)

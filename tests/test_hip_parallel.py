@@ -37,7 +37,10 @@ def _single_process(case):
             EpsIndependent.eps = eps
         losses.append(float(trainer.step(batch).item()))
         grads.append(trainer.flat.flat_grad.detach().cpu().clone())
-    return losses, grads, trainer.flat.flat.detach().cpu().clone()
+    st = trainer.opt.state[trainer.flat.flat]
+    adam = dict(exp_avg=st["exp_avg"].detach().cpu().clone(), exp_avg_sq=st["exp_avg_sq"].detach().cpu().clone(),
+                step=float(st["step"]))
+    return losses, grads, trainer.flat.flat.detach().cpu().clone(), adam
 
 
 @pytest.mark.timeout(600)
@@ -55,7 +58,7 @@ def test_two_rank_trainer_equals_global_batch_step(name, tmp_path):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    ref_losses, ref_grads, ref_w = _single_process(case)
+    ref_losses, ref_grads, ref_w, ref_adam = _single_process(case)
     res = [torch.load(o, weights_only=True) for o in outs]
     # replicas agree bit for bit with each other (same averaged gradient, same Adam state)
     assert torch.equal(res[0]["weights"], res[1]["weights"])
@@ -66,18 +69,21 @@ def test_two_rank_trainer_equals_global_batch_step(name, tmp_path):
         assert abs(mean_loss - ref_losses[s]) <= 2e-6 * abs(ref_losses[s]), (s, mean_loss, ref_losses[s])
         g, want = res[0]["grads"][s].double(), ref_grads[s].double()
         assert (g - want).abs().max() <= 1e-6 * want.abs().max(), (s, float((g - want).abs().max()), float(want.abs().max()))
-    # post-Adam weights after the steps.  Adam divides by sqrt(v): its step is lr * sign-like in the gradient, so the
-    # 1e-6-of-max summation-order difference asserted above moves a weight by (difference / |entry|) * lr.  Entries whose
-    # gradient is >= 1e-3 of the largest in every step (difference <= 1e-3 of the entry) must agree to 1e-5 = 1 % of lr;
-    # entries down to 1e-4 of the largest (difference <= 1e-2 of the entry) to 1e-4; below that the same noise is a large
-    # fraction of the entry itself, up to its sign: Adam's own bound of about a step per step, and no more than 1e-4 of
-    # all weights may be beyond 1e-5 at all
+    # the optimizer path: Adam's moments are linear (exp_avg) and quadratic (exp_avg_sq) in the averaged gradients, so the
+    # 1e-6-of-max agreement of the gradients carries over to them at 1e-6 / 2e-6 of their largest entry, and the step
+    # counts are equal -- this pins the all-reduce -> Adam hand-over without Adam's sign-like division in the way
+    assert res[0]["step"] == res[1]["step"] == ref_adam["step"] == float(len(ref_grads))
+    for key, tol in (("exp_avg", 1e-6), ("exp_avg_sq", 2e-6)):
+        assert torch.equal(res[0][key], res[1][key]), key
+        got, want = res[0][key].double(), ref_adam[key].double()
+        assert (got - want).abs().max() <= tol * want.abs().max(), (key, float((got - want).abs().max()), float(want.abs().max()))
+    # post-Adam weights after the steps: a sanity bound only (the moments above are the sharp check).  Adam divides by
+    # sqrt(v): its step is lr * sign-like in the gradient, so an entry whose gradient is at the summation-order noise can move
+    # by up to a step per step; entries with a gradient >= 1e-3 of the largest must agree to 1 % of lr
     lr, steps = 1e-3, len(ref_grads)
     d = (res[0]["weights"].double() - ref_w.double()).abs()
     gmin = torch.stack([g.double().abs() for g in ref_grads]).min(0).values
     gmax = max(float(g.abs().max()) for g in ref_grads)
-    big, mid = gmin >= 1e-3 * gmax, gmin >= 1e-4 * gmax
+    big = gmin >= 1e-3 * gmax
     assert d[big].max() <= 1e-5, float(d[big].max())
-    assert d[mid].max() <= 1e-4, float(d[mid].max())
     assert d.max() <= 2.5 * lr * steps, float(d.max())
-    assert float((d > 1e-5).double().mean()) <= 1e-4, float((d > 1e-5).double().mean())

@@ -11,8 +11,11 @@ shift 2 || true
 ARGS="--config $CFG $@"
 NAME=${TAG}_${CFG}
 OUT=gpurun_out/prof_$NAME
+case " $ARGS " in *" --gpus "*) echo "profile_round.sh profiles the single-GPU run only (bench.py --gpus N spawns ranks: not under rocprofv3)"; exit 2;; esac
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+export TMPDIR=/tmp
+cd "$ROOT"
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; cut -c1-200 $OUT/bench.json
 P="--no-cpu-baseline"
