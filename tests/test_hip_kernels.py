@@ -456,7 +456,7 @@ def test_mlp_x6_stack_forward_and_backward_match_float64():
 def test_mlp_x6_split_edge_values():
     """Edge semantics of the three-term split (csrc/mlp_x6_kernel.hip, x6m_split) against fp32 ``F.linear``:
     (1) huge finite inputs up to 3.38e38 (just under the largest bf16, 3.3895e38): exact like any other value;
-    (2) subnormal-range and zero inputs: exact;
+    (2) subnormal-range and zero inputs: zero to within a denormal flush;
     (3) a non-finite input (inf / nan) makes that point's outputs non-finite, as the reference's fp32 addmm does (inf * w, and
         inf - inf = nan across mixed signs), and leaves every other point untouched;
     (4) DOCUMENTED DEVIATION: a finite input in (3.3895e38, FLT_MAX] rounds to bf16 infinity in the first term, so its point
@@ -484,7 +484,7 @@ def test_mlp_x6_split_edge_values():
     assert torch.isfinite(y[0, finite_pts]).all()
     for p in (0, 1, 2, 6):
         m = (x[0, p].double().abs() @ lin.weight.double().abs().T).max()
-        assert float((y[0, p].double() - ref64[0, p]).abs().max()) <= 1e-6 * float(m), p
+        assert float((y[0, p].double() - ref64[0, p]).abs().max()) <= 1e-6 * float(m) + 1e-36, p  # (+ denormal flush)
     for p in (3, 4, 5):
         assert not torch.isfinite(y[0, p]).any(), p
     assert torch.isfinite(torch.nn.functional.linear(x[0, 5], lin.weight.cpu())).all()  # (fp32 itself is still finite there)
