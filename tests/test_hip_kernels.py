@@ -469,6 +469,7 @@ def test_mlp_x6_split_edge_values():
     lin = torch.nn.Linear(256, 256)
     lin.weight.data = torch.randn(256, 256, generator=g) * 1e-3  # (products and sums stay finite)
     lin.bias.data.zero_()
+    W = lin.weight.detach().clone()
     pts = 64
     x = torch.randn(1, pts, 256, generator=g)
     x[0, 1, :] = torch.where(torch.rand(256, generator=g) < 0.5, 3.38e38, -3.38e38)   # (1)
@@ -478,16 +479,16 @@ def test_mlp_x6_split_edge_values():
     x[0, 4, 9] = float("nan")
     x[0, 5, 11] = 3.40e38                                                              # (4)
     with torch.no_grad():
-        ref64 = torch.nn.functional.linear(x.double(), lin.weight.double())
+        ref64 = torch.nn.functional.linear(x.double(), W.double())
         y = FN.unpack_pt(mlp_x6.run_stack(FN.pack_pt(x.to(DEV)), pts, [lin.to(DEV)], [False]), pts, 256).cpu()
     finite_pts = [p for p in range(pts) if p not in (3, 4, 5)]
     assert torch.isfinite(y[0, finite_pts]).all()
     for p in (0, 1, 2, 6):
-        m = (x[0, p].double().abs() @ lin.weight.double().abs().T).max()
+        m = (x[0, p].double().abs() @ W.double().abs().T).max()
         assert float((y[0, p].double() - ref64[0, p]).abs().max()) <= 1e-6 * float(m) + 1e-36, p  # (+ denormal flush)
     for p in (3, 4, 5):
         assert not torch.isfinite(y[0, p]).any(), p
-    assert torch.isfinite(torch.nn.functional.linear(x[0, 5], lin.weight.cpu())).all()  # (fp32 itself is still finite there)
+    assert torch.isfinite(torch.nn.functional.linear(x[0, 5], W)).all()  # (fp32 itself is still finite there)
 
 
 def test_mlp_x6_stack_with_output_layer_rows_matches_float64():
