@@ -330,6 +330,69 @@ int npf_mlp_x6_run_rows(const npf_x6_layer_t *layers, int32_t n_layers, const fl
                         float *y, const float *out_w, const float *out_b, float *out_rows, int32_t n_tasks,
                         int32_t tiles_per_task, void *stream);
 
+/* ---- x6 programs: whole sides of the model as ONE launch on the bf16 matrix pipe, fp32 results -------------------------
+ * The generalisation of npf_mlp_x6_run: a straight-line program of up to NPF_X6_MAX_OPS ops on the register-resident activation
+ * `cur` of every point (width F = 128 or 256 features, PT32 tensors with exactly F features), every multiply an fp32 product
+ * as six bf16 products of exact three-term splits (see above).  Besides the shared-weight layers of the flat MLPs
+ * (npf/architectures/mlp.py:95-109) an op can
+ *  - take PER-TASK weights (w_task_stride != 0): the task's keys / values as three-term images (npf_x6_task_images) -- the two
+ *    contractions of DotAttender (npf/architectures/attention.py:204-220 scores, :151 attn . values) and of its backward;
+ *  - apply the softmax of attention.py:158-164 to its result (softmax_n keys, in registers, wavefront shuffles), or the softmax
+ *    backward to its input (sbwd_p);
+ *  - form its input from [points][4] rows through a [4][in_n] matrix (+ bias, ReLU): the first layer of the x-encoder and of
+ *    the XY-encoder's resizer (Linear(1 -> r), Linear(2 -> 32); mlp.py:96) at no HBM traffic, or the dgrad of a 256 -> 4 layer;
+ *  - run without a multiply (w_img == NULL): an elementwise step (mask + store: the end of a dgrad chain).
+ * Per op, in this order:
+ *   input side   cur <- in_pt                           (a new PT32 input; else cur = the previous op's result)
+ *                cur <- [relu](in_w^T rows + in_b)      (in_rows; features >= in_n are zero)
+ *                cur += pre_add                         (PT32)
+ *                cur <- mask > 0 ? cur : 0              (mask: PT32; mask_bits: one uint64 per lane and half tile, see below)
+ *                cur <- sbwd_scale * P * (cur - <cur, P>)   (sbwd_p = P, PT32)
+ *                store_in <- cur (PT32);  store_in_bits <- (cur > 0)
+ *   multiply     cur <- W cur + bias                    (w_img: [3][F][F] bf16 three-term image, + task * w_task_stride BYTES;
+ *                                                        bias [F] or NULL, + task * bias_task_stride floats)
+ *   output side  cur += addend (PT32);  relu;  softmax over the first softmax_n features of softmax_scale * cur;
+ *                store_out <- cur (PT32);  store_bits <- (cur > 0)
+ * Bit tensors: [n_tasks * tiles_per_task][2][64] uint64, bit 4 b + e of lane (p, g) = feature 16 b + 4 g + e of point p of
+ * the half tile.  Rows tensors: [n_tasks * tiles_per_task * 32][4] (the points of a task fill whole tiles). */
+#define NPF_X6_MAX_OPS 12
+typedef struct npf_x6_op {
+  const float *in_pt;
+  const float *in_rows;
+  const float *in_w;
+  const float *in_b;
+  const float *pre_add;
+  const float *mask;
+  const unsigned long long *mask_bits;
+  const float *sbwd_p;
+  float *store_in;
+  unsigned long long *store_in_bits;
+  const void *w_img;
+  int64_t w_task_stride;
+  const float *bias;
+  int64_t bias_task_stride;
+  const float *addend;
+  float *store_out;
+  unsigned long long *store_bits;
+  int32_t in_n;        /* outputs of the rows prologue (a multiple of 16, <= F) */
+  int32_t in_relu;
+  int32_t relu;
+  int32_t softmax_n;   /* 0 = no softmax */
+  float softmax_scale;
+  float sbwd_scale;
+  int32_t reserved[2];
+} npf_x6_op_t;
+/* out_rows != NULL: a F -> 4 layer behind the program, out_rows[point][n] = sum_f out_w[n][f] cur[f] + out_b[n] (the decoder's
+ * output layer, mlp.py:109).  per_task != 0: every workgroup stays inside one task (required by per-task weights / biases).
+ * width: 128 or 256. */
+int npf_x6_run(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const float *out_b, float *out_rows,
+               int32_t n_tasks, int32_t tiles_per_task, int32_t per_task, int32_t width, void *stream);
+/* The three-term images of a PT32 tensor src [n_tasks][tiles_per_task][F/4][32][4] taken as per-task weights, F = width:
+ *   row_img [n_tasks][3][F][F] bf16: W[n = point][k = feature]   (scores = K q, dP = V dO), points >= pts are zero rows;
+ *   tr_img  [n_tasks][3][F][F] bf16: W[n = feature][k = point]   (attn . V, dq = K^T dS), points >= pts are zero columns;
+ * both k-permuted like npf_cast_bf16_weights.  pts <= F points per task.  Either destination may be NULL. */
+int npf_x6_task_images(const float *src, int32_t n_tasks, int32_t pts, int32_t width, void *row_img, void *tr_img, void *stream);
+
 int npf_version(void);
 
 #ifdef __cplusplus

@@ -72,6 +72,19 @@ class NpfX6Layer(C.Structure):
                 ("relu", C.c_int32), ("reserved", C.c_int32)]
 
 
+NPF_X6_MAX_OPS = 12
+
+
+class NpfX6Op(C.Structure):
+    _fields_ = [("in_pt", C.c_void_p), ("in_rows", C.c_void_p), ("in_w", C.c_void_p), ("in_b", C.c_void_p),
+                ("pre_add", C.c_void_p), ("mask", C.c_void_p), ("mask_bits", C.c_void_p), ("sbwd_p", C.c_void_p),
+                ("store_in", C.c_void_p), ("store_in_bits", C.c_void_p), ("w_img", C.c_void_p), ("w_task_stride", C.c_int64),
+                ("bias", C.c_void_p), ("bias_task_stride", C.c_int64), ("addend", C.c_void_p), ("store_out", C.c_void_p),
+                ("store_bits", C.c_void_p), ("in_n", C.c_int32), ("in_relu", C.c_int32), ("relu", C.c_int32),
+                ("softmax_n", C.c_int32), ("softmax_scale", C.c_float), ("sbwd_scale", C.c_float), ("reserved", C.c_int32 * 2)]
+
+
+assert C.sizeof(NpfX6Op) == 17 * 8 + 8 * 4
 assert C.sizeof(NpfOp) == 80 and C.sizeof(NpfProgram) == 32 + 80 * NPF_MAX_OPS and C.sizeof(NpfWgradJob) == 72 and C.sizeof(NpfWprepJob) == 32
 
 # name -> (restype, argtypes); must list every symbol declared in include/npf_hip.h
@@ -96,6 +109,8 @@ SIGNATURES = {
     "npf_merge_heads": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "npf_mlp_x6_run": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _i32, _i32, _p]),
     "npf_mlp_x6_run_rows": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
+    "npf_x6_run": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "npf_x6_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "npf_version": (C.c_int, []),
 }
 

@@ -135,7 +135,10 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         if T == 0:
             raise ValueError("no target points")
         Xc_pt = self._xenc_pt(X_cntxt, with_tr=self._attentive) if C > 0 else None
-        Xt_pt = self._xenc_pt(X_trgt)
+        if self._fused_target_side(C, T):
+            Xt_pt, self._X_trgt_raw = None, X_trgt  # (the target side runs as one x6 program from the raw features)
+        else:
+            Xt_pt = self._xenc_pt(X_trgt)
         R = self._encode_globally_pt(Xc_pt, Y_cntxt, B, C)
         if self.encoded_path in ["latent", "both"]:
             z_samples, q_zCc, q_zCct = self._latent_path_pt(R, C, Xt_pt, Y_trgt, B, T)
@@ -183,6 +186,10 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
 
     # ------------------------------------------------------------------ PT-level stages
     _attentive = False  # attentive subclasses also keep feature-major copies of keys / values
+
+    def _fused_target_side(self, C, T) -> bool:
+        """Does ``forward`` hand the whole target side (x-encoder, attention, decoder) to one x6 program (x6.py)."""
+        return False
 
     def _xenc_pt(self, X, with_tr=False) -> PTensor:
         B, P, dx = X.shape
@@ -430,6 +437,11 @@ class AttnCNP(NeuralProcessFamily):
 
     dflt_Modules = CNP.dflt_Modules
 
+    def _fused_target_side(self, C, T) -> bool:
+        from . import x6
+
+        return type(self) is AttnCNP and self.encoded_path == "deterministic" and x6.target_side_usable(self, C, T)
+
     # reference stage API
     def encode_globally(self, X_cntxt, Y_cntxt):
         B, C, _ = X_cntxt.shape
@@ -480,6 +492,10 @@ class AttnCNP(NeuralProcessFamily):
         return ch
 
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
+        if Xt_pt is None:  # (forward left the target side to the fused x6 program: x-encoder, attention, decoder in one launch)
+            from . import x6
+
+            return x6.target_side(self, self._X_trgt_raw, Xc_pt, R)
         ch = Chain(B, T, Xt_pt.t.device, wg_per_task=True)
         if C == 0:
             ch.input_pt(torch.zeros(pt_shape(B, T, self.r_dim), device=Xt_pt.t.device), self.r_dim)

@@ -1,0 +1,376 @@
+"""x6 programs (``npf_x6_run``, ``csrc/x6_kernel.hip``): whole sides of the model as one launch with every multiply an fp32
+product on the bf16 matrix pipe (three exact bf16 terms per operand, six cross products, fp32 accumulation).
+
+``target_side`` is the fused target side of an attentive deterministic model (AttnCNP with scaled-dot attention,
+npf/neuralproc/attnnp.py:118-131 + base.py:327-367): x-encoder from the raw frequencies, cross attention over the task's context
+points, decoder and its output layer -- ONE launch forward, ONE launch for the dgrad of all of it, then the weight / key / value
+gradient jobs.  ``context_side`` is the x-encoder + XY-encoder of the context points (attnnp.py:105-116) the same way.
+Nothing here computes on the CPU; there is no fallback (callers test ``*_usable`` and otherwise take the chain path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import chain as CH
+from . import functional as FN
+
+# NPF_NO_X6_FUSED=1: the fused sides are off (the chain / mlp_x6 launches of round 2 run instead)
+ENABLED = os.environ.get("NPF_NO_X6_FUSED", "0") != "1"
+WIDTH = 256
+
+
+class Program:
+    """A list of ``npf_x6_op_t`` + geometry; ``launch()`` calls ``npf_x6_run``."""
+
+    def __init__(self, n_tasks: int, tiles: int, per_task: bool, width: int = WIDTH):
+        self.n_tasks, self.tiles, self.per_task, self.width = n_tasks, tiles, per_task, width
+        self.ops: List[dict] = []
+        self.tail = None  # (W [4, F], b [4] or None, rows [points, 4])
+
+    def op(self, **kw) -> "Program":
+        self.ops.append(kw)
+        return self
+
+    @staticmethod
+    def _ptr(t, what):
+        if t is None:
+            return None
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError(f"x6 program operand {what} must be a contiguous device tensor")
+        return t.data_ptr()
+
+    def _pt_ok(self, t, what):
+        want = (self.n_tasks, self.tiles, self.width // 4, 32, 4)
+        if t is not None and (tuple(t.shape) != want or t.dtype != torch.float32):
+            raise ValueError(f"x6 program operand {what}: PT32 tensor {tuple(t.shape)} {t.dtype}, expected {want} float32")
+
+    def launch(self) -> None:
+        if len(self.ops) > L.NPF_X6_MAX_OPS:
+            raise RuntimeError(f"x6 program longer than NPF_X6_MAX_OPS={L.NPF_X6_MAX_OPS}")
+        arr = (L.NpfX6Op * len(self.ops))()
+        F, pts = self.width, self.n_tasks * self.tiles * 32
+        flops = 0
+        nbytes = 0
+        for j, o in enumerate(self.ops):
+            for k in ("in_pt", "pre_add", "mask", "sbwd_p", "store_in", "addend", "store_out"):
+                self._pt_ok(o.get(k), k)
+                setattr(arr[j], k, self._ptr(o.get(k), k))
+                nbytes += pts * F * 4 if o.get(k) is not None else 0
+            for k in ("mask_bits", "store_in_bits", "store_bits"):
+                t = o.get(k)
+                if t is not None and (tuple(t.shape) != (self.n_tasks, self.tiles, 2, 64) or t.dtype != torch.int64):
+                    raise ValueError(f"x6 program operand {k}: bits tensor {tuple(t.shape)} {t.dtype}")
+                setattr(arr[j], k, self._ptr(t, k))
+                nbytes += pts * F // 8 if t is not None else 0
+            if o.get("in_rows") is not None:
+                rows, w, b = o["in_rows"], o["in_w"], o.get("in_b")
+                n = w.shape[1]
+                if tuple(rows.shape) != (self.n_tasks, self.tiles * 32, 4) or w.shape[0] != 4 or n % 16 or n > F:
+                    raise ValueError(f"x6 rows prologue: rows {tuple(rows.shape)}, matrix {tuple(w.shape)}")
+                if b is not None and tuple(b.shape) != (n,):
+                    raise ValueError("x6 rows prologue: bias shape")
+                arr[j].in_rows, arr[j].in_w, arr[j].in_b = L.ptr(rows), L.ptr(w), L.ptr(b)
+                arr[j].in_n, arr[j].in_relu = n, int(bool(o.get("in_relu", False)))
+                flops += 2 * 4 * n * pts
+                nbytes += pts * 16
+            img = o.get("img")
+            if img is not None:
+                per_task = bool(o.get("img_per_task", False))
+                want = (self.n_tasks, 3, F, F) if per_task else (3, F, F)
+                if tuple(img.shape) != want or img.dtype != torch.bfloat16 or not img.is_contiguous():
+                    raise ValueError(f"x6 program weight image {tuple(img.shape)} {img.dtype}, expected {want} bfloat16")
+                arr[j].w_img = img.data_ptr()
+                arr[j].w_task_stride = 3 * F * F * 2 if per_task else 0
+                bias = o.get("bias")
+                if bias is not None:
+                    bpt = bool(o.get("bias_per_task", False))
+                    if tuple(bias.shape) != ((self.n_tasks, F) if bpt else (F,)):
+                        raise ValueError(f"x6 program bias {tuple(bias.shape)}")
+                    arr[j].bias = L.ptr(bias)
+                    arr[j].bias_task_stride = F if bpt else 0
+                arr[j].relu = int(bool(o.get("relu", False)))
+                arr[j].softmax_n = int(o.get("softmax_n", 0))
+                arr[j].softmax_scale = float(o.get("softmax_scale", 1.0))
+                flops += 2 * o.get("true_k", F) * o.get("true_n", F) * pts
+                nbytes += 3 * 2 * F * F * (self.n_tasks if per_task else 1)
+            elif any(o.get(k) is not None for k in ("bias", "addend", "store_out", "store_bits")) or o.get("relu") or o.get("softmax_n"):
+                raise ValueError("x6 program: an op without a multiply has no output side")
+            arr[j].sbwd_scale = float(o.get("sbwd_scale", 1.0))
+        tail = self.tail
+        if tail is not None:
+            flops += 2 * 4 * F * pts
+            nbytes += pts * 16
+        if CH.PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().npf_x6_run(arr, len(self.ops), L.ptr(tail[0]) if tail else None,
+                                    L.ptr(tail[1]) if (tail and tail[1] is not None) else None,
+                                    L.ptr(tail[2]) if tail else None, self.n_tasks, self.tiles, int(self.per_task), F,
+                                    L.stream_ptr()), "npf_x6_run")
+        if CH.PROFILE is not None:
+            ev1.record()
+            CH.PROFILE.append(("x6_program_kernel", flops, ev0, ev1, nbytes))
+
+
+def task_images(pt: torch.Tensor, pts: int, row: bool = True, tr: bool = True, width: int = WIDTH):
+    """Three-term images of a PT32 tensor [n_tasks, tiles, F/4, 32, 4] taken as per-task weights (``npf_x6_task_images``):
+    (row image W[n = point][k = feature], transposed image W[n = feature][k = point]), each [n_tasks, 3, F, F] bf16 or None."""
+    n_tasks = pt.shape[0]
+    if tuple(pt.shape) != (n_tasks, CH.tiles_of(pts), width // 4, 32, 4) or pts > width:
+        raise ValueError(f"task_images: PT32 tensor {tuple(pt.shape)} for {pts} points x {width} features")
+    mk = lambda: torch.empty((n_tasks, 3, width, width), dtype=torch.bfloat16, device=pt.device)  # noqa: E731
+    ri, ti = (mk() if row else None), (mk() if tr else None)
+    if CH.PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    L.check(L.load().npf_x6_task_images(L.ptr(pt.detach().contiguous()), n_tasks, pts, width,
+                                        ri.data_ptr() if row else None, ti.data_ptr() if tr else None, L.stream_ptr()),
+            "npf_x6_task_images")
+    if CH.PROFILE is not None:
+        ev1.record()
+        CH.PROFILE.append(("x6_task_images_kernel", 0, ev0, ev1,
+                           pt.numel() * 4 + (int(row) + int(tr)) * n_tasks * 3 * width * width * 2))
+    return ri, ti
+
+
+def _weight_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List[List[torch.Tensor]]:
+    from .mlp_x6 import _three_term_images
+
+    return _three_term_images(Ws, kinds)
+
+
+def _bits(n_tasks, tiles, dev):
+    return torch.empty((n_tasks, tiles, 2, 64), dtype=torch.int64, device=dev)
+
+
+def _pad_rows4(X: torch.Tensor) -> torch.Tensor:
+    """[B, P, d] (d <= 4) -> contiguous [B, P, 4], zero padded."""
+    d = X.shape[-1]
+    if d == 4:
+        return X.contiguous()
+    return torch.nn.functional.pad(X, (0, 4 - d)).contiguous()
+
+
+def _first_layer_matrix(W: torch.Tensor, n_out: int) -> torch.Tensor:
+    """nn.Linear weight [n, d] (d <= 4) -> the rows-prologue matrix [4, n_out] = W^T, zero padded."""
+    n, d = W.shape
+    out = torch.zeros((4, n_out), dtype=torch.float32, device=W.device)
+    out[:d, :n] = W.detach().t()
+    return out
+
+
+def _pad_out(W: torch.Tensor, b: Optional[torch.Tensor]):
+    """The F -> n_out (<= 4) output layer as a [4, F] matrix and a [4] bias."""
+    n = W.shape[0]
+    if n == 4:
+        return W.detach().contiguous(), (b.detach().contiguous() if b is not None else None)
+    Wp = torch.zeros((4, W.shape[1]), dtype=torch.float32, device=W.device)
+    Wp[:n] = W.detach()
+    bp = None
+    if b is not None:
+        bp = torch.zeros((4,), dtype=torch.float32, device=W.device)
+        bp[:n] = b.detach()
+    return Wp, bp
+
+
+class _TargetSideFn(torch.autograd.Function):
+    """rows [B, T, n_out] = decoder(x_encoder(X_trgt), attention(x_encoder(X_trgt), K, V)).
+
+    Arguments: X [B, T, dx] raw target features; K_pt, V_pt PT32 [B, tilesC, 64, 32, 4] (encoded context points /
+    their representations), C context points; ``spec`` = (n_xenc, n_res, n_flat): numbers of 256 -> 256 layers of the x-encoder
+    behind its first layer, of the resizer, of the flat MLP in front of its output layer; params = W, b pairs in the order
+    x-encoder (first layer, then the 256 -> 256 ones), resizer, flat, output layer."""
+
+    @staticmethod
+    def forward(ctx, X, K_pt, V_pt, C, scale, spec, *params):
+        n_x, n_res, n_flat = spec
+        B, T, dx = X.shape
+        dev = X.device
+        tiles = T // 32
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        W1, b1 = Ws[0], bs[0]
+        W_out, b_out = Ws[-1], bs[-1]
+        n_out = W_out.shape[0]
+        mid_W, mid_b = Ws[1:-1], bs[1:-1]  # the 256 -> 256 layers: x-encoder rest, resizer, flat
+        train = any(ctx.needs_input_grad)
+        imgs = _weight_images(mid_W, (1, 2) if train else (1,))
+        fw = imgs[0]
+        K_row, K_tr = task_images(K_pt, C, row=True, tr=train)
+        V_row, V_tr = task_images(V_pt, C, row=train, tr=True)
+        X4 = _pad_rows4(X.detach())
+        W1p = _first_layer_matrix(W1, WIDTH)
+        pt = lambda: CH.pt_empty(B, T, WIDTH, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=True)
+        saved_acts, saved_bits = [], []
+        # x-encoder: first layer in the prologue, then its 256 -> 256 layers (ReLU on all but the last, mlp.py:95-109)
+        h1 = pt() if train else None
+        bits_h1 = _bits(B, tiles, dev) if train else None
+        Xt_enc = pt()
+        cur_in = h1
+        for i in range(n_x):
+            last = i == n_x - 1
+            o = dict(img=fw[i], bias=mid_b[i].detach() if mid_b[i] is not None else None, relu=not last)
+            if i == 0:
+                o.update(in_rows=X4, in_w=W1p, in_b=b1.detach() if b1 is not None else None, in_relu=True, store_in=h1,
+                         store_in_bits=bits_h1)
+            if last:
+                o["store_out"] = Xt_enc
+            elif train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                saved_acts.append(o["store_out"])
+                saved_bits.append(o["store_bits"])
+            prog.op(**o)
+        # attention (attention.py:129-164, 204-220): scores = K q, softmax(scale .), attn . V
+        P = pt() if train else None
+        prog.op(img=K_row, img_per_task=True, softmax_n=C, softmax_scale=scale, store_out=P, true_n=C)
+        R_trgt = pt() if train else None
+        prog.op(img=V_tr, img_per_task=True, store_out=R_trgt, true_k=C)
+        # decoder: resizer, merge relu(x1 + .) (encoders.py:178-179), flat MLP
+        for i in range(n_res + n_flat):
+            j = n_x + i
+            o = dict(img=fw[j], bias=mid_b[j].detach() if mid_b[j] is not None else None, relu=True)
+            if i == n_res - 1:
+                o["addend"] = Xt_enc
+            if train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                saved_acts.append(o["store_out"])
+                saved_bits.append(o["store_bits"])
+            prog.op(**o)
+        rows = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+        Wo, bo = _pad_out(W_out, b_out)
+        prog.tail = (Wo, bo, rows)
+        prog.launch()
+        ctx.geom = (B, T, tiles, dx, C, float(scale), n_out)
+        ctx.spec = spec
+        ctx.has_b = [b is not None for b in bs]
+        ctx.set_materialize_grads(False)
+        if train:
+            ctx.n_acts, ctx.n_bits = len(saved_acts), len(saved_bits)
+            ctx.save_for_backward(X4, h1, bits_h1, Xt_enc, P, R_trgt, *saved_acts, *saved_bits, *imgs[1], V_row, K_tr, Wo)
+        return rows[..., :n_out] if n_out != 4 else rows
+
+    @staticmethod
+    def backward(ctx, g):
+        n_x, n_res, n_flat = ctx.spec
+        n_mid = n_x + n_res + n_flat
+        n_par = 2 * (n_mid + 2)
+        if g is None:
+            return (None,) * (6 + n_par)
+        B, T, tiles, dx, C, scale, n_out = ctx.geom
+        sv = list(ctx.saved_tensors)
+        X4, h1, bits_h1, Xt_enc, P, R_trgt = sv[:6]
+        acts = sv[6:6 + ctx.n_acts]
+        bits = sv[6 + ctx.n_acts:6 + ctx.n_acts + ctx.n_bits]
+        rest = sv[6 + ctx.n_acts + ctx.n_bits:]
+        bw, (V_row, K_tr, Wo) = rest[:n_mid], rest[n_mid:]
+        dev = g.device
+        g4 = g.contiguous() if n_out == 4 else torch.nn.functional.pad(g, (0, 4 - n_out)).contiguous()
+        pt = lambda: CH.pt_empty(B, T, WIDTH, dev)  # noqa: E731
+        # the saved outputs by layer: x-encoder hidden layers (n_x - 1 of them), then resizer + flat (all ReLU layers)
+        x_acts, x_bits = acts[:n_x - 1], bits[:n_x - 1]
+        d_acts, d_bits = acts[n_x - 1:], bits[n_x - 1:]
+        prog = Program(B, tiles, per_task=True)
+        dz = [None] * n_mid  # dZ of every 256 -> 256 layer (index as in the forward: x-encoder, resizer, flat)
+        # decoder layers, last to first
+        for i in range(n_res + n_flat - 1, -1, -1):
+            j = n_x + i
+            dz[j] = pt()
+            o = dict(mask_bits=d_bits[i], store_in=dz[j], img=bw[j])
+            if i == n_res + n_flat - 1:
+                o.update(in_rows=g4, in_w=Wo)  # the dgrad of the output layer in the prologue
+            prog.op(**o)
+        # attention backward: dO -> dP = V dO ; dS = softmax'(dP) ; dq = K^T dS, + the merge's gradient wrt x1 (fan-in)
+        dO, dS = pt(), pt()
+        prog.op(store_in=dO, img=V_row, img_per_task=True, true_n=C)
+        prog.op(sbwd_p=P, sbwd_scale=scale, store_in=dS, img=K_tr, img_per_task=True, addend=dz[n_x + n_res - 1], true_k=C)
+        # x-encoder, last to first; the first layer's dZ behind its ReLU mask closes the program
+        for i in range(n_x - 1, -1, -1):
+            dz[i] = pt()
+            o = dict(store_in=dz[i], img=bw[i])
+            if i < n_x - 1:
+                o["mask_bits"] = x_bits[i]
+            prog.op(**o)
+        dz1 = pt()
+        prog.op(mask_bits=bits_h1, store_in=dz1)
+        prog.launch()
+        # weight / key / value gradients
+        jobs, grads = [], []
+        # (the first layer's fan-in zero-padded to 4, like the chain path pads skinny first layers)
+        dW1p = torch.empty((WIDTH, 4), dtype=torch.float32, device=dev)
+        db1 = torch.empty((WIDTH,), dtype=torch.float32, device=dev) if ctx.has_b[0] else None
+        jobs.append(dict(dZ=dz1, A=FN._pack(X4), N=WIDTH, K=4, dW=dW1p, db=db1))
+        grads += [None, db1]  # (dW1 sliced out of dW1p after the launch)
+        ins = [h1, *x_acts, R_trgt, *d_acts[:-1]]  # input of every 256 -> 256 layer
+        for j in range(n_mid):
+            dW = torch.empty((WIDTH, WIDTH), dtype=torch.float32, device=dev)
+            db = torch.empty((WIDTH,), dtype=torch.float32, device=dev) if ctx.has_b[1 + j] else None
+            jobs.append(dict(dZ=dz[j], A=ins[j], N=WIDTH, K=WIDTH, dW=dW, db=db))
+            grads += [dW, db]
+        dz_out = torch.zeros(CH.pt_shape(B, T, 4), dtype=torch.float32, device=dev)
+        dz_out[:, :, 0] = g4.view(B, tiles, 32, 4)
+        dWo = torch.empty((n_out, WIDTH), dtype=torch.float32, device=dev)
+        dbo = torch.empty((n_out,), dtype=torch.float32, device=dev) if ctx.has_b[-1] else None
+        jobs.append(dict(dZ=dz_out, A=d_acts[-1], N=n_out, K=WIDTH, dW=dWo, db=dbo))
+        grads += [dWo, dbo]
+        dK = torch.empty(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dV = torch.empty(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        if dV is not None:
+            jobs.append(dict(dZ=P, A=dO, N=C, K=WIDTH, dW=dV, per_task=True, ldz=WIDTH))  # (P has 256 features per tile)
+        if dK is not None:
+            jobs.append(dict(dZ=dS, A=Xt_enc, N=C, K=WIDTH, dW=dK, per_task=True, ldz=WIDTH))
+        CH.run_wgrad(jobs, B, T, dev)
+        grads[0] = dW1p[:, :dx].contiguous() if dx != 4 else dW1p
+        return (None, dK, dV, None, None, None, *grads)
+
+
+def _square(lins, width=WIDTH) -> bool:
+    return all(l.in_features == width and l.out_features == width for l in lins)
+
+
+def target_side_usable(model, C: int, T: int) -> bool:
+    """Does the fused target side cover this model and batch: AttnCNP-style deterministic path with scaled-dot attention over
+    128 < C <= 256 context points, every wide layer 256 -> 256, no residual / dropout, whole tiles of targets."""
+    from .architectures import MLP, DotAttender
+
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32"):
+        return False
+    xe, dec, att = model.x_encoder, model.decoder, getattr(model, "attender", None)
+    if not isinstance(att, DotAttender) or att.kq_size != WIDTH or att.value_size != WIDTH:
+        return False
+    if not (WIDTH // 2 < C <= WIDTH and T % 32 == 0 and T > 0):
+        return False
+    if not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == WIDTH and xe.output_size == WIDTH
+            and not xe.is_res and not (xe.dropout_p > 0 and xe.training)):
+        return False
+    if not (dec.is_sum_merge and isinstance(dec.flat_module, MLP)):
+        return False
+    fm, rs = dec.flat_module, dec.resizer
+    for m in (fm, rs):
+        if m.is_res or (m.dropout_p > 0 and m.training):
+            return False
+    if not (_square(rs.layers()) and _square([fm.to_hidden, *fm.linears]) and fm.out.in_features == WIDTH
+            and fm.out.out_features <= 4):
+        return False
+    n_x, n_res, n_flat = len(xe.linears) + 1, len(rs.layers()), len(fm.linears) + 1
+    # forward: n_x + 2 + n_res + n_flat ops; dgrad: the same + 1
+    return n_x + 2 + n_res + n_flat + 1 <= L.NPF_X6_MAX_OPS
+
+
+def target_side(model, X_trgt: torch.Tensor, K: CH.PTensor, V: CH.PTensor) -> torch.Tensor:
+    """The decoder's sufficient statistics [B, T, 2 dy] of an attentive deterministic model from the raw target features and
+    the context side's PT32 outputs (``target_side_usable`` must hold)."""
+    xe, dec, att = model.x_encoder, model.decoder, model.attender
+    fm, rs = dec.flat_module, dec.resizer
+    lins = [xe.to_hidden, *xe.linears, xe.out, *rs.layers(), fm.to_hidden, *fm.linears, fm.out]
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    spec = (len(xe.linears) + 1, len(rs.layers()), len(fm.linears) + 1)
+    scale = 1.0 / math.sqrt(att.kq_size) if att.is_scale else 1.0
+    return _TargetSideFn.apply(X_trgt, K.t, V.t, K.pts, scale, spec, *params)

@@ -1,0 +1,146 @@
+"""GPU parity tests of the x6 programs (csrc/x6_kernel.hip, npf_gwwaveform_amd/x6.py) through the C ABI: the fused target side
+of an attentive model (x-encoder, scaled-dot cross attention, decoder, output layer; npf/neuralproc/attnnp.py:118-131,
+npf/architectures/attention.py:129-164,204-220, encoders.py:175-183, mlp.py:95-109) and its autograd against a float64
+evaluation of the same fp32 parameters -- the arithmetic is fp32 (three exact bf16 terms per operand), so the gates are the
+fp32 ones of SURVEY.md 8c: 1e-5 of max|ref| on outputs, 1e-4 on gradients."""
+import math
+import warnings
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def assert_close(got, ref, tol=1e-5, what=""):
+    got = got.detach().cpu().double().numpy()
+    ref = ref.detach().cpu().double().numpy()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    m = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max()
+    assert err <= tol * m, f"{what}: max|d|={err:.3e} > {tol:.0e} * max|ref|={m:.3e}"
+
+
+def _unpermute(img):
+    """[..., rows, K] k-permuted image -> natural column order (position 8 g + i <- column 4 g + i, 8 g + 4 + i <- 16 + 4 g + i)."""
+    K = img.shape[-1]
+    idx = torch.empty(K, dtype=torch.long)
+    for q in range(K):
+        grp, r = divmod(q, 32)
+        gq, i = divmod(r, 8)
+        idx[q] = 32 * grp + (4 * gq + i if i < 4 else 16 + 4 * gq + (i - 4))
+    out = torch.empty_like(img)
+    out[..., idx] = img
+    return out
+
+
+@pytest.mark.parametrize("pts", [256, 200, 130])
+def test_task_images_are_exact_three_term_splits(pts):
+    """npf_x6_task_images: the sum of the three bf16 terms is the fp32 value (to 2^-24), rows / columns beyond the task's points
+    are zero, both orientations."""
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    g = torch.Generator().manual_seed(pts)
+    rows = torch.randn(3, pts, 256, generator=g) * torch.logspace(-3, 3, 256)
+    ri, ti = x6.task_images(FN.pack_pt(rows.to(DEV)), pts)
+    for img, want in ((ri, rows), (ti, rows.transpose(1, 2))):
+        full = torch.zeros(3, 256, 256, dtype=torch.float64)
+        if want.shape[1] == pts:
+            full[:, :pts] = want.double()
+        else:
+            full[:, :, :pts] = want.double()
+        terms = _unpermute(img.cpu().double())  # [3 tasks, 3 terms, 256, 256]
+        got = terms.sum(1)
+        assert float((got - full).abs().max()) <= 2.0 ** -23 * float(full.abs().max())
+        assert float(((got - full).abs() / full.abs().clamp_min(1e-30)).max()) <= 2.0 ** -22
+        # the leading term is the bf16 rounding of the value
+        assert torch.equal(terms[:, 0].float(), full.float().to(torch.bfloat16).float())
+
+
+def _build(r=256, L=4, dx=1, dy=2, seed=0):
+    import npf_gwwaveform_amd as A
+
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = A.AttnCNP(dx, dy, attention="scaledot", r_dim=r,
+                      XYEncoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, is_force_hid_smaller=True, hidden_size=r),
+                                                   is_sum_merge=True),
+                      Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, hidden_size=r), is_sum_merge=True))
+    with torch.no_grad():  # (biases are zero at initialisation: give them values)
+        for k, p in m.named_parameters():
+            if k.endswith(".bias"):
+                p.uniform_(-0.05, 0.05)
+    return m.to(DEV)
+
+
+def _target_side_f64(model, X, K, V):
+    """float64 statement of the target side with the model's fp32 parameters."""
+    d = lambda t: t.detach().double().cpu()  # noqa: E731
+    P = {k: d(v).requires_grad_(True) for k, v in model.named_parameters()}
+    lin = lambda x, pre: torch.nn.functional.linear(x, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+
+    def mlp(x, pre, n_lin):
+        h = torch.relu(lin(x, pre + ".to_hidden"))
+        for i in range(n_lin):
+            h = torch.relu(lin(h, f"{pre}.linears.{i}"))
+        return lin(h, pre + ".out")
+
+    Xt = mlp(X, "x_encoder", len(model.x_encoder.linears))
+    logits = torch.einsum("bkd,bqd->bqk", K, Xt) / math.sqrt(Xt.shape[-1])
+    R = torch.bmm(logits.softmax(-1), V)
+    x2 = mlp(R, "decoder.resizer", len(model.decoder.resizer.linears))
+    out = mlp(torch.relu(Xt + x2), "decoder.flat_module", len(model.decoder.flat_module.linears))
+    return out, P
+
+
+@pytest.mark.parametrize("B,C,T,L,dx,dy", [(2, 256, 64, 4, 1, 2), (3, 200, 96, 2, 2, 1), (1, 129, 32, 1, 1, 2)])
+def test_fused_target_side_matches_float64(B, C, T, L, dx, dy):
+    from npf_gwwaveform_amd import chain as CH
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    model = _build(L=L, dx=dx, dy=dy, seed=B * 7 + C)
+    assert x6.target_side_usable(model, C, T)
+    g = torch.Generator().manual_seed(C + T)
+    X = torch.rand(B, T, dx, generator=g) * 2 - 1
+    K = torch.randn(B, C, 256, generator=g) * 0.5
+    V = torch.randn(B, C, 256, generator=g) * 0.5
+    w = torch.randn(B, T, 2 * dy, generator=g)
+    Kd, Vd = K.to(DEV).requires_grad_(True), V.to(DEV).requires_grad_(True)
+    rows = x6.target_side(model, X.to(DEV), CH.PTensor(FN.pack_pt(Kd), C, 256), CH.PTensor(FN.pack_pt(Vd), C, 256))
+    assert tuple(rows.shape) == (B, T, 2 * dy)
+    (rows * w.to(DEV)).sum().backward()
+    Kr, Vr = K.double().requires_grad_(True), V.double().requires_grad_(True)
+    ref, P = _target_side_f64(model, X.double(), Kr, Vr)
+    (ref * w.double()).sum().backward()
+    assert_close(rows, ref, tol=1e-5, what="target side rows")
+    assert_close(Kd.grad, Kr.grad, tol=1e-4, what="dK")
+    assert_close(Vd.grad, Vr.grad, tol=1e-4, what="dV")
+    for k, p in model.named_parameters():
+        if k.startswith("xy_encoder"):
+            continue
+        assert p.grad is not None, k
+        assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
+
+
+def test_fused_target_side_inference_equals_training_forward():
+    """Without gradients the program stores nothing but what it re-reads: same rows."""
+    from npf_gwwaveform_amd import chain as CH
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    model = _build(L=2, seed=5)
+    g = torch.Generator().manual_seed(9)
+    X = (torch.rand(2, 64, 1, generator=g) * 2 - 1).to(DEV)
+    K = FN.pack_pt((torch.randn(2, 256, 256, generator=g) * 0.5).to(DEV))
+    V = FN.pack_pt((torch.randn(2, 256, 256, generator=g) * 0.5).to(DEV))
+    a = x6.target_side(model, X, CH.PTensor(K, 256, 256), CH.PTensor(V, 256, 256))
+    with torch.no_grad():
+        b = x6.target_side(model, X, CH.PTensor(K, 256, 256), CH.PTensor(V, 256, 256))
+    assert torch.equal(a, b)
