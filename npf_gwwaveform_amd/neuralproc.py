@@ -134,12 +134,20 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         T = X_trgt.shape[1]
         if T == 0:
             raise ValueError("no target points")
-        Xc_pt = self._xenc_pt(X_cntxt, with_tr=self._attentive) if C > 0 else None
-        if self._fused_target_side(C, T):
+        fused_t = self._fused_target_side(C, T)
+        if self._fused_context_side(C):
+            # x-encoder + XY-encoder of the context points as one x6 program (x6.py); the pooling stays the subclass's
+            from . import x6
+
+            Xc_pt, R_pts = x6.context_side(self, X_cntxt, Y_cntxt)
+            R = self._pool_pt(R_pts, B)
+        else:
+            Xc_pt = self._xenc_pt(X_cntxt, with_tr=self._attentive and not fused_t) if C > 0 else None
+            R = self._encode_globally_pt(Xc_pt, Y_cntxt, B, C)
+        if fused_t:
             Xt_pt, self._X_trgt_raw = None, X_trgt  # (the target side runs as one x6 program from the raw features)
         else:
             Xt_pt = self._xenc_pt(X_trgt)
-        R = self._encode_globally_pt(Xc_pt, Y_cntxt, B, C)
         if self.encoded_path in ["latent", "both"]:
             z_samples, q_zCc, q_zCct = self._latent_path_pt(R, C, Xt_pt, Y_trgt, B, T)
         else:
@@ -190,6 +198,12 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
     def _fused_target_side(self, C, T) -> bool:
         """Does ``forward`` hand the whole target side (x-encoder, attention, decoder) to one x6 program (x6.py)."""
         return False
+
+    def _fused_context_side(self, C) -> bool:
+        """Does ``forward`` hand x-encoder + XY-encoder of the context points to one x6 program (x6.py)."""
+        from . import x6
+
+        return hasattr(self, "xy_encoder") and hasattr(self, "_pool_pt") and x6.context_side_usable(self, C)
 
     def _xenc_pt(self, X, with_tr=False) -> PTensor:
         B, P, dx = X.shape
@@ -366,7 +380,10 @@ class CNP(NeuralProcessFamily):
         """-> row-major R [B, 1, r] (np.py:86-101)."""
         if P == 0:
             return torch.zeros(B, 1, self.r_dim, device=Y.device)
-        R_pts = self._xyenc_pt(X_enc, Y)
+        return self._pool_pt(self._xyenc_pt(X_enc, Y), B)
+
+    def _pool_pt(self, R_pts: PTensor, B):
+        """np.py:95: the mean over the context points of the per-point representations -> row-major [B, 1, r]."""
         return FN.mean_agg(R_pts.t, R_pts.pts, self.r_dim)[:, : self.r_dim].reshape(B, 1, self.r_dim)
 
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
@@ -463,6 +480,10 @@ class AttnCNP(NeuralProcessFamily):
         if P == 0:
             return None
         return self._xyenc_pt(X_enc, Y)
+
+    def _pool_pt(self, R_pts: PTensor, B):
+        """attnnp.py:105-116: no pooling, one representation per context point."""
+        return R_pts
 
     def _attend_into(self, ch, Xc_pt, R, Xt_pt, C, T, tap_x1: bool = False):
         """cur of ``ch`` <- attention of the targets over the context (attnnp.py:118-131): fused into

@@ -374,3 +374,188 @@ def target_side(model, X_trgt: torch.Tensor, K: CH.PTensor, V: CH.PTensor) -> to
     spec = (len(xe.linears) + 1, len(rs.layers()), len(fm.linears) + 1)
     scale = 1.0 / math.sqrt(att.kq_size) if att.is_scale else 1.0
     return _TargetSideFn.apply(X_trgt, K.t, V.t, K.pts, scale, spec, *params)
+
+
+class _ContextSideFn(torch.autograd.Function):
+    """(Xc_enc, R) PT32 [B, tilesC, 64, 32, 4] each = x_encoder(X_cntxt), xy_encoder(Xc_enc, Y_cntxt) (attnnp.py:105-116 /
+    np.py:86-95 up to the pooling; encoders.py:175-183: flat(relu(x1 + resizer(y)))) in one launch; the dgrad of both in one
+    launch.  ``spec`` = (n_xenc, n_flat): 256 -> 256 layers of the x-encoder behind its first layer, of the flat MLP (its output
+    layer included); params = W, b pairs: x-encoder, resizer (dy -> h, h -> 256), flat."""
+
+    @staticmethod
+    def forward(ctx, X, Y, spec, *params):
+        n_x, n_flat = spec
+        B, Cn, dx = X.shape
+        dy = Y.shape[-1]
+        dev = X.device
+        tiles = Cn // 32
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        W1, b1 = Ws[0], bs[0]
+        x_W, x_b = Ws[1:1 + n_x], bs[1:1 + n_x]
+        Wr1, br1, Wr2, br2 = Ws[1 + n_x], bs[1 + n_x], Ws[2 + n_x], bs[2 + n_x]
+        f_W, f_b = Ws[3 + n_x:], bs[3 + n_x:]
+        h = Wr1.shape[0]
+        train = any(ctx.needs_input_grad)
+        Wr2p = torch.zeros((WIDTH, WIDTH), dtype=torch.float32, device=dev)  # (the h -> 256 layer as a 256-input layer:
+        Wr2p[:, :h] = Wr2.detach()                                           #  the input's other registers are zero)
+        imgs = _weight_images([*x_W, Wr2p, *f_W], (1, 2) if train else (1,))
+        fw = imgs[0]
+        X4, Y4 = _pad_rows4(X.detach()), _pad_rows4(Y.detach())
+        pt = lambda: CH.pt_empty(B, Cn, WIDTH, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False)
+        acts, bits = [], []
+        h1 = pt() if train else None
+        bits_h1 = _bits(B, tiles, dev) if train else None
+        Xc_enc = pt()
+        for i in range(n_x):
+            last = i == n_x - 1
+            o = dict(img=fw[i], bias=x_b[i].detach() if x_b[i] is not None else None, relu=not last)
+            if i == 0:
+                o.update(in_rows=X4, in_w=_first_layer_matrix(W1, WIDTH), in_b=b1.detach() if b1 is not None else None,
+                         in_relu=True, store_in=h1, store_in_bits=bits_h1)
+            if last:
+                o["store_out"] = Xc_enc
+            elif train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                acts.append(o["store_out"])
+                bits.append(o["store_bits"])
+            prog.op(**o)
+        # resizer(y): first layer in the prologue (h features), second layer + x1 + ReLU = the merge
+        hy = pt() if train else None
+        bits_hy = _bits(B, tiles, dev) if train else None
+        o = dict(in_rows=Y4, in_w=_first_layer_matrix(Wr1, h), in_b=br1.detach() if br1 is not None else None, in_relu=True,
+                 store_in=hy, store_in_bits=bits_hy, img=fw[n_x], bias=br2.detach() if br2 is not None else None, relu=True,
+                 addend=Xc_enc, true_k=h)
+        if train:
+            o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+            acts.append(o["store_out"])
+            bits.append(o["store_bits"])
+        prog.op(**o)
+        R = pt()
+        for i in range(n_flat):
+            last = i == n_flat - 1
+            o = dict(img=fw[n_x + 1 + i], bias=f_b[i].detach() if f_b[i] is not None else None, relu=not last)
+            if last:
+                o["store_out"] = R
+            elif train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                acts.append(o["store_out"])
+                bits.append(o["store_bits"])
+            prog.op(**o)
+        prog.launch()
+        ctx.geom = (B, Cn, tiles, dx, dy, h)
+        ctx.spec = spec
+        ctx.has_b = [b is not None for b in bs]
+        ctx.set_materialize_grads(False)
+        if train:
+            ctx.n_acts = len(acts)
+            ctx.save_for_backward(X4, Y4, h1, bits_h1, hy, bits_hy, *acts, *bits, *imgs[1])
+        return Xc_enc, R
+
+    @staticmethod
+    def backward(ctx, gK, gR):
+        n_x, n_flat = ctx.spec
+        n_par = 2 * (1 + n_x + 2 + n_flat)
+        if gK is None and gR is None:
+            return (None,) * (3 + n_par)
+        B, Cn, tiles, dx, dy, h = ctx.geom
+        sv = list(ctx.saved_tensors)
+        X4, Y4, h1, bits_h1, hy, bits_hy = sv[:6]
+        acts, bits = sv[6:6 + ctx.n_acts], sv[6 + ctx.n_acts:6 + 2 * ctx.n_acts]
+        bw = sv[6 + 2 * ctx.n_acts:]
+        dev = X4.device
+        pt = lambda: CH.pt_empty(B, Cn, WIDTH, dev)  # noqa: E731
+        x_acts, x_bits = acts[:n_x - 1], bits[:n_x - 1]
+        m_act, m_bits = acts[n_x - 1], bits[n_x - 1]          # the merge's output
+        f_acts, f_bits = acts[n_x:], bits[n_x:]                 # flat hidden outputs (n_flat - 1 of them)
+        prog = Program(B, tiles, per_task=False)
+        jobs, grads = [], [None] * n_par
+
+        def wjob(pos, dZ, A, N, K, **kw):
+            dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            db = torch.empty((N,), dtype=torch.float32, device=dev) if ctx.has_b[pos] else None
+            jobs.append(dict(dZ=dZ, A=A, N=N, K=K, dW=dW, db=db, **kw))
+            grads[2 * pos], grads[2 * pos + 1] = dW, db
+            return dW
+
+        dz_m = None
+        if gR is not None:
+            gR = gR.contiguous()
+            # flat MLP, last to first; the output layer's dZ is the incoming gradient itself
+            f_in = [m_act, *f_acts]
+            for i in range(n_flat - 1, -1, -1):
+                o = dict(img=bw[n_x + 1 + i])
+                if i == n_flat - 1:
+                    o["in_pt"] = gR
+                    dz = gR
+                else:
+                    dz = pt()
+                    o.update(mask_bits=f_bits[i], store_in=dz)
+                prog.op(**o)
+                wjob(1 + n_x + 2 + i, dz, f_in[i], WIDTH, WIDTH)
+            # the merge relu(x1 + W_r2 hy + b): its dZ is also the gradient wrt x1; then back through the h-wide first layer
+            dz_m, dz_hy = pt(), pt()
+            prog.op(mask_bits=m_bits, store_in=dz_m, img=bw[n_x])
+            prog.op(mask_bits=bits_hy, store_in=dz_hy)
+            wjob(1 + n_x + 1, dz_m, hy, WIDTH, h, lda=WIDTH)
+            dWr1 = wjob(1 + n_x, dz_hy, FN._pack(Y4), h, 4, ldz=WIDTH)
+        # x-encoder: gradient of Xc_enc = what the attention sends back for the keys + the merge's x1 gradient
+        if gK is not None or dz_m is not None:
+            first = dict(in_pt=gK.contiguous(), pre_add=dz_m) if gK is not None else dict(in_pt=dz_m)
+            x_in = [h1, *x_acts]
+            for i in range(n_x - 1, -1, -1):
+                dz = pt()
+                o = dict(store_in=dz, img=bw[i])
+                if i == n_x - 1:
+                    o.update(first)
+                else:
+                    o["mask_bits"] = x_bits[i]
+                prog.op(**o)
+                wjob(1 + i, dz, x_in[i], WIDTH, WIDTH)
+            dz1 = pt()
+            prog.op(mask_bits=bits_h1, store_in=dz1)
+            dW1p = wjob(0, dz1, FN._pack(X4), WIDTH, 4)
+        prog.launch()
+        CH.run_wgrad(jobs, B, Cn, dev)
+        if gR is not None and dy != 4:
+            grads[2 * (1 + n_x)] = dWr1[:, :dy].contiguous()
+        if (gK is not None or dz_m is not None) and dx != 4:
+            grads[0] = dW1p[:, :dx].contiguous()
+        return (None, None, None, *grads)
+
+
+def context_side_usable(model, C: int) -> bool:
+    """Does the fused context side cover this model and batch: stock MLP x-encoder (<= 4 inputs) and sum-merge MLP XY-encoder
+    with 256-wide layers, no residual / dropout, a two-layer resizer (dy -> h -> 256, h a multiple of 16), whole tiles."""
+    from .architectures import MLP, MergeFlatInputs
+
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or C <= 0 or C % 32:
+        return False
+    xe, xy = model.x_encoder, getattr(model, "xy_encoder", None)
+    if not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == WIDTH and xe.output_size == WIDTH
+            and not xe.is_res and not (xe.dropout_p > 0 and xe.training)):
+        return False
+    if not (isinstance(xy, MergeFlatInputs) and xy.is_sum_merge and isinstance(xy.flat_module, MLP)):
+        return False
+    fm, rs = xy.flat_module, xy.resizer
+    for m in (fm, rs):
+        if m.is_res or (m.dropout_p > 0 and m.training):
+            return False
+    if not (_square([fm.to_hidden, *fm.linears, fm.out]) and len(rs.linears) == 0 and rs.input_size <= 4
+            and rs.output_size == WIDTH and rs.hidden_size % 16 == 0 and rs.hidden_size <= WIDTH):
+        return False
+    n_x, n_flat = len(xe.linears) + 1, len(fm.linears) + 2
+    return n_flat + 2 + n_x + 1 <= L.NPF_X6_MAX_OPS
+
+
+def context_side(model, X_cntxt: torch.Tensor, Y_cntxt: torch.Tensor):
+    """(encoded context points, their per-point representations) as :class:`~chain.PTensor` s (``context_side_usable``)."""
+    xe, xy = model.x_encoder, model.xy_encoder
+    fm, rs = xy.flat_module, xy.resizer
+    lins = [xe.to_hidden, *xe.linears, xe.out, rs.to_hidden, rs.out, fm.to_hidden, *fm.linears, fm.out]
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    Cn = X_cntxt.shape[1]
+    Xc, R = _ContextSideFn.apply(X_cntxt, Y_cntxt, (len(xe.linears) + 1, len(fm.linears) + 2), *params)
+    return CH.PTensor(Xc, Cn, WIDTH), CH.PTensor(R, Cn, WIDTH)

@@ -144,3 +144,47 @@ def test_fused_target_side_inference_equals_training_forward():
     with torch.no_grad():
         b = x6.target_side(model, X, CH.PTensor(K, 256, 256), CH.PTensor(V, 256, 256))
     assert torch.equal(a, b)
+
+
+def _context_side_f64(model, X, Y):
+    d = lambda t: t.detach().double().cpu()  # noqa: E731
+    P = {k: d(v).requires_grad_(True) for k, v in model.named_parameters()}
+    lin = lambda x, pre: torch.nn.functional.linear(x, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+
+    def mlp(x, pre, n_lin):
+        h = torch.relu(lin(x, pre + ".to_hidden"))
+        for i in range(n_lin):
+            h = torch.relu(lin(h, f"{pre}.linears.{i}"))
+        return lin(h, pre + ".out")
+
+    Xc = mlp(X, "x_encoder", len(model.x_encoder.linears))
+    x2 = mlp(Y, "xy_encoder.resizer", 0)
+    R = mlp(torch.relu(Xc + x2), "xy_encoder.flat_module", len(model.xy_encoder.flat_module.linears))
+    return Xc, R, P
+
+
+@pytest.mark.parametrize("B,C,L,dx,dy", [(2, 256, 4, 1, 2), (3, 64, 2, 2, 1), (1, 32, 1, 1, 3)])
+def test_fused_context_side_matches_float64(B, C, L, dx, dy):
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    model = _build(L=L, dx=dx, dy=dy, seed=B * 11 + C)
+    assert x6.context_side_usable(model, C) and not x6.context_side_usable(model, C + 1)
+    g = torch.Generator().manual_seed(C + L)
+    X = torch.rand(B, C, dx, generator=g) * 2 - 1
+    Y = torch.randn(B, C, dy, generator=g)
+    wk, wr = torch.randn(B, C, 256, generator=g), torch.randn(B, C, 256, generator=g)
+    Xc, R = x6.context_side(model, X.to(DEV), Y.to(DEV))
+    (FN.unpack_pt(Xc.t, C, 256) * wk.to(DEV)).sum().backward(retain_graph=True)
+    gk_only = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    (FN.unpack_pt(R.t, C, 256) * wr.to(DEV)).sum().backward()
+    Xc_r, R_r, P = _context_side_f64(model, X.double(), Y.double())
+    ((Xc_r * wk.double()).sum() + (R_r * wr.double()).sum()).backward()
+    assert_close(FN.unpack_pt(Xc.t, C, 256), Xc_r, tol=1e-5, what="Xc_enc")
+    assert_close(FN.unpack_pt(R.t, C, 256), R_r, tol=1e-5, what="R")
+    assert set(gk_only) == {k for k in P if k.startswith("x_encoder")}  # (a gradient for the keys alone stays in the x-encoder)
+    for k, p in model.named_parameters():
+        if k.startswith("decoder"):
+            continue
+        assert p.grad is not None, k
+        assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
