@@ -318,8 +318,10 @@ class _TargetSideFn(torch.autograd.Function):
         dbo = torch.empty((n_out,), dtype=torch.float32, device=dev) if ctx.has_b[-1] else None
         jobs.append(dict(dZ=dz_out, A=d_acts[-1], N=n_out, K=WIDTH, dW=dWo, db=dbo))
         grads += [dWo, dbo]
-        dK = torch.empty(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        dV = torch.empty(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        # (context points that do not fill their last tile: the padding rows of dK / dV are zero -- their keys have no weight)
+        mk = torch.zeros if C % 32 else torch.empty
+        dK = mk(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dV = mk(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         if dV is not None:
             jobs.append(dict(dZ=P, A=dO, N=C, K=WIDTH, dW=dV, per_task=True, ldz=WIDTH))  # (P has 256 features per tile)
         if dK is not None:
@@ -343,7 +345,7 @@ def target_side_usable(model, C: int, T: int) -> bool:
     xe, dec, att = model.x_encoder, model.decoder, getattr(model, "attender", None)
     if not isinstance(att, DotAttender) or att.kq_size != WIDTH or att.value_size != WIDTH:
         return False
-    if not (WIDTH // 2 < C <= WIDTH and T % 32 == 0 and T > 0):
+    if not (WIDTH // 2 < C <= WIDTH and T > 0):
         return False
     if not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == WIDTH and xe.output_size == WIDTH
             and not xe.is_res and not (xe.dropout_p > 0 and xe.training)):
@@ -373,7 +375,12 @@ def target_side(model, X_trgt: torch.Tensor, K: CH.PTensor, V: CH.PTensor) -> to
         params += [lin.weight, lin.bias]
     spec = (len(xe.linears) + 1, len(rs.layers()), len(fm.linears) + 1)
     scale = 1.0 / math.sqrt(att.kq_size) if att.is_scale else 1.0
-    return _TargetSideFn.apply(X_trgt, K.t, V.t, K.pts, scale, spec, *params)
+    T = X_trgt.shape[1]
+    Tp = CH.pad32(T)
+    if Tp != T:  # whole tiles of targets: the padding points (x = 0) are computed and dropped, their gradients are zero
+        X_trgt = torch.nn.functional.pad(X_trgt, (0, 0, 0, Tp - T))
+    rows = _TargetSideFn.apply(X_trgt, K.t, V.t, K.pts, scale, spec, *params)
+    return rows if Tp == T else rows[:, :T].contiguous()
 
 
 class _ContextSideFn(torch.autograd.Function):
@@ -529,7 +536,7 @@ def context_side_usable(model, C: int) -> bool:
     with 256-wide layers, no residual / dropout, a two-layer resizer (dy -> h -> 256, h a multiple of 16), whole tiles."""
     from .architectures import MLP, MergeFlatInputs
 
-    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or C <= 0 or C % 32:
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or C <= 0:
         return False
     xe, xy = model.x_encoder, getattr(model, "xy_encoder", None)
     if not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == WIDTH and xe.output_size == WIDTH
@@ -557,5 +564,9 @@ def context_side(model, X_cntxt: torch.Tensor, Y_cntxt: torch.Tensor):
     for lin in lins:
         params += [lin.weight, lin.bias]
     Cn = X_cntxt.shape[1]
+    if Cn % 32:  # whole tiles: the padding points are computed (finite values) and never read -- every consumer knows ``pts``
+        pad = CH.pad32(Cn) - Cn
+        X_cntxt = torch.nn.functional.pad(X_cntxt, (0, 0, 0, pad))
+        Y_cntxt = torch.nn.functional.pad(Y_cntxt, (0, 0, 0, pad))
     Xc, R = _ContextSideFn.apply(X_cntxt, Y_cntxt, (len(xe.linears) + 1, len(fm.linears) + 2), *params)
     return CH.PTensor(Xc, Cn, WIDTH), CH.PTensor(R, Cn, WIDTH)
