@@ -68,9 +68,11 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default=None, choices=["fp32", "bf16"],
                     help="fp32 | bf16 (bf16 MFMA products in the MLP stacks, attention and weight gradients; fp32 accumulation)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="N = 1 replays the train step from a captured HIP graph by default (Trainer(use_graph=True): the same "
+                    help="the train step is replayed from captured HIP graphs by default (Trainer(use_graph=True): the same "
                          "kernels in the same order; the input range check stays in the step as a device reduction and is "
-                         "read after the timed region); this flag launches every step eagerly instead")
+                         "read after the timed region; N > 1: forward + backward graph, one all-reduce of the flat gradient, "
+                         "Adam graph); this flag launches every step eagerly instead (N > 1: bucketed all-reduce overlapped "
+                         "with the backward pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args(argv)
@@ -309,23 +311,31 @@ def timed_region(step, n_steps: int, sync):
 
 def profile_launches(step, n_prof: int, rank: int, sync, CH):
     """Instrumented pass after the timed region: HIP events around every kernel launch on the launch
-    stream (rank 0); every rank runs the steps because a train step contains the gradient all-reduce."""
+    stream (rank 0); every rank runs the steps because a train step contains the gradient all-reduce.
+    Returns (agg, kernels, launches): per-kernel totals, their JSON form, and the launches of ONE step in
+    order (kernel, what it computes, ms, algorithmic GFLOP / GB) -- the attention path is a row of its own there."""
     if rank == 0:
         CH.PROFILE = []
     for i in range(n_prof):
         step(i)
     sync()
     if rank != 0:
-        return None, {}
+        return None, {}, []
     prof, CH.PROFILE = CH.PROFILE, None
-    if os.environ.get("NPF_BENCH_VERBOSE"):
-        per = len(prof) // n_prof
-        for name, flops, e0, e1, nbytes in prof[-per:]:
-            ms = e0.elapsed_time(e1)
-            print(f"  {name:14s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s "
-                  f"{nbytes * 1e-9:7.3f} GB (algorithmic) {nbytes / ms * 1e-6:7.0f} GB/s", file=sys.stderr)
+    per = len(prof) // n_prof
+    launches = []
+    for rec in prof[-per:]:
+        name, flops, e0, e1, nbytes = rec[:5]
+        ms = e0.elapsed_time(e1)
+        launches.append({"kernel": name, "what": rec[5] if len(rec) > 5 else "", "ms": round(ms, 4),
+                         "algorithmic_gflop": round(flops * 1e-9, 3), "tflops": round(flops / ms * 1e-9, 1) if ms > 0 else 0.0,
+                         "algorithmic_hbm_gb": round(nbytes * 1e-9, 4)})
+        if os.environ.get("NPF_BENCH_VERBOSE"):
+            print(f"  {name:22s} {ms:8.3f} ms {flops * 1e-9:9.2f} GFLOP {flops / ms * 1e-9:7.1f} TF/s "
+                  f"{nbytes * 1e-9:7.3f} GB (algorithmic) {nbytes / ms * 1e-6:7.0f} GB/s  {launches[-1]['what']}", file=sys.stderr)
     agg = {}
-    for name, flops, e0, e1, nbytes in prof:
+    for rec in prof:
+        name, flops, e0, e1, nbytes = rec[:5]
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
@@ -341,24 +351,41 @@ def profile_launches(step, n_prof: int, rank: int, sync, CH):
                                             "XY-encoder flat module), fp32 operands as three exact bf16 terms, six bf16 MFMAs per "
                                             "product group -- fp32 results on the bf16 pipe (DESIGN.md 3.2 / 3.7); NPF_NO_MLP_X6=1 "
                                             "keeps them in the fp32 chains")
+    if "x6_program_kernel" in kernels:
+        kernels["x6_program_kernel"]["note"] = ("npf_x6_run: a whole side of the model per launch (x-encoder, scaled-dot attention, "
+                                                "decoder / XY-encoder; forward or dgrad), every product an fp32 product on the bf16 "
+                                                "pipe (three exact bf16 terms per operand, six v_mfma_f32_16x16x32_bf16 per product "
+                                                "group, fp32 accumulation; DESIGN.md 3.8); NPF_NO_X6_FUSED=1 = the round-2 launches")
     if "wgrad_kernel" in kernels and CH.COMPUTE_DTYPE != "bf16" and CH.WGRAD_X6:
         # (the rate can exceed the fp32 MFMA peak: these launches run on the bf16 matrix pipe)
         kernels["wgrad_kernel"]["note"] = ("wgrad_x6_kernel: fp32 operands split exactly into three bf16 terms, six "
                                            "v_mfma_f32_16x16x32_bf16 per product group, fp32 accumulation -- an fp32 result on "
                                            "the bf16 pipe (DESIGN.md 3.2); NPF_NO_WGRAD_X6=1 = the fp32-MFMA kernel")
-    return agg, kernels
+    return agg, kernels, launches
 
 
 # fp32 kernels that multiply on the bf16 matrix pipe (three exact bf16 terms per operand): priced against bf16 peak / 6
 SPLIT_KERNELS = set()
 
 
-def roofline_of(agg, dtype: str, tag: str, preset: bool, n_steps_prof: int = 1):
-    """The dominant kernel (most device time) against its roofline.  fp32 launches are bound by the fp32
-    MFMA rate.  bf16 launches have 1/16 of those MFMA cycles and are priced against both rooflines; the line
-    carries the larger fraction (the binding one)."""
+def _pipe(name: str, dtype: str):
+    """(peak TFLOP/s, its name) of the matrix pipe a kernel's products run on."""
+    if dtype == "bf16":
+        return PEAK_BF16_TFLOPS, "bf16 MFMA"
+    if name in SPLIT_KERNELS:
+        return PEAK_BF16_TFLOPS / 6.0, "bf16 MFMA / 6"
+    return PEAK_F32_TFLOPS, "fp32 MFMA"
+
+
+def roofline_of(agg, dtype: str, tag: str, preset: bool, n_steps_prof: int = 1, ms_per_step=None, launches=None):
+    """The dominant kernel (most device time) against its roofline.  fp32 launches on v_mfma_f32_16x16x4_f32 are bound by the
+    fp32 MFMA rate; fp32 launches that multiply three-term bf16 splits by the dense bf16 rate / 6.  bf16 launches have 1/16
+    of the fp32 MFMA cycles and are priced against both rooflines; the line carries the larger fraction (the binding one).
+    ``step_frac``: the time the step's algorithmic FLOPs would take with every kernel at the peak of its own pipe, over the
+    measured step time."""
     name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
     tf, gbps = fl / sec * 1e-12, nb / sec * 1e-9
+    peak, pipe = _pipe(name, dtype)
     if dtype == "bf16":
         f_m, f_h = tf / PEAK_BF16_TFLOPS, gbps / PEAK_HBM_GBPS
         if f_h >= f_m:
@@ -367,21 +394,26 @@ def roofline_of(agg, dtype: str, tag: str, preset: bool, n_steps_prof: int = 1):
             roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": f_m}
         roof["frac_mfma_bf16"], roof["frac_hbm"] = f_m, f_h
         roof["achieved_tflops_algorithmic"], roof["achieved_gbps_algorithmic"] = tf, gbps
-    elif name in SPLIT_KERNELS:
-        # fp32 results from six bf16 MFMAs per product group: the pipe's dense bf16 rate / 6 is this kernel's roofline
-        roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS / 6.0, "unit": "TFLOP/s",
-                "frac": tf / (PEAK_BF16_TFLOPS / 6.0), "achieved_gbps_algorithmic": gbps,
-                "peak_is": "dense bf16 MFMA rate / 6 (fp32 operands as three exact bf16 terms, six cross products; DESIGN.md 3.2)"}
     else:
-        roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / PEAK_F32_TFLOPS, "achieved_gbps_algorithmic": gbps}
+        roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "achieved_gbps_algorithmic": gbps, "frac_hbm_algorithmic": gbps / PEAK_HBM_GBPS}
+        if name in SPLIT_KERNELS:
+            # fp32 results from six bf16 MFMAs per product group: the pipe's dense bf16 rate / 6 is this kernel's roofline
+            roof["peak_is"] = "dense bf16 MFMA rate / 6 (fp32 operands as three exact bf16 terms, six cross products; DESIGN.md 3.2)"
     # every kernel of the step against its own roofline (the block above is the one with the most device time)
     roof["by_kernel"] = {
         k: {"ms_per_step": round(v[2] / max(1, n_steps_prof) * 1e3, 3),
-            "frac": round((v[1] / v[2] * 1e-12) / ((PEAK_BF16_TFLOPS / 6.0) if (k in SPLIT_KERNELS and dtype != "bf16") else
-                                                   (PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS)), 3),
-            "of": ("bf16 MFMA / 6" if (k in SPLIT_KERNELS and dtype != "bf16") else ("bf16 MFMA" if dtype == "bf16" else "fp32 MFMA"))}
+            "frac": round((v[1] / v[2] * 1e-12) / _pipe(k, dtype)[0], 3), "of": _pipe(k, dtype)[1],
+            "frac_hbm_algorithmic": round(v[3] / v[2] * 1e-9 / PEAK_HBM_GBPS, 3)}
         for k, v in agg.items()}
+    if ms_per_step:
+        # seconds the step's algorithmic work takes at the peak of each kernel's pipe / measured step time
+        t_min = sum(v[1] / max(1, n_steps_prof) / (_pipe(k, dtype)[0] * 1e12) for k, v in agg.items())
+        roof["step_frac"] = round(t_min / (ms_per_step * 1e-3), 4)
+        roof["step_frac_is"] = "sum over kernels of (algorithmic FLOPs / peak of the kernel's pipe) / measured step time"
+    if launches:
+        roof["launches"] = [dict(l, frac=round(l["tflops"] / _pipe(l["kernel"], dtype)[0], 3), of=_pipe(l["kernel"], dtype)[1])
+                            for l in launches]
     roof["traffic"] = None
     # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     # rocprofv3 --pmc passes of this same command), condensed by tools/summarize_profiles.py into
@@ -397,6 +429,8 @@ def roofline_of(agg, dtype: str, tag: str, preset: bool, n_steps_prof: int = 1):
                 roof["traffic"] = k["hbm_bytes_per_launch"]
                 roof["traffic_unit"] = "bytes/launch"
                 roof["traffic_source"] = os.path.relpath(f, ROOT)
+                if "mfma_busy_frac" in k:
+                    roof["mfma_busy_frac_pmc"] = k["mfma_busy_frac"]
                 break
     return roof
 
@@ -429,9 +463,9 @@ def main_decode(args, rank, world, dev, sync):
     value = world * B * T * args.steps / elapsed
     roofline, kernels = None, {}
     if not args.no_roofline:
-        agg, kernels = profile_launches(step, 2, rank, sync, CH)
+        agg, kernels, launches = profile_launches(step, 2, rank, sync, CH)
         if rank == 0:
-            roofline = roofline_of(agg, "fp32", "c5", args.preset, 2)
+            roofline = roofline_of(agg, "fp32", "c5", args.preset, 2, elapsed / args.steps * 1e3, launches)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_decode(r, L, T)
@@ -464,7 +498,7 @@ def main_train(args, rank, world, dev, sync, rehearsal):
         A.set_compute_dtype("bf16")
     model, crit = build_model(args.model, args.r, args.layers, dev, args.attention)
     n_params = sum(p.numel() for p in model.parameters())
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not args.no_graph
     trainer = Trainer(model, crit, lr=1e-3, world=world, use_graph=use_graph)
     batches = [synthetic_waveform_batch(B, C, T, 1234 + rank * 10**6 + i, dev) for i in range(4)]
 
@@ -487,18 +521,39 @@ def main_train(args, rank, world, dev, sync, rehearsal):
     value = world * B * T * args.steps / elapsed
     loss_val = float(loss.item())
     trainer.check_inputs()  # (graph mode: the range check's verdict, deferred to this sync point)
+    # beside the headline: (1) N > 1, graph mode: the all-reduce between the two replayed graphs, timed by HIP events over
+    # another K steps; (2) the same K steps launched eagerly (bucketed all-reduce overlapped with the backward pass) with the
+    # phases of the step timed -- how much of the exchange the backward pass hides there, and what the host costs
+    def timed_with_phases(fn):
+        trainer.phase_events = []
+        el, _, _ = timed_region(fn, args.steps, sync)
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        ph = trainer.phase_times()
+        trainer.phase_events = None
+        return el / args.steps * 1e3, ph
+
+    phases = {}
+    if use_graph and world > 1:
+        _, phases = timed_with_phases(step)
+    ms_eager, phases_eager = timed_with_phases(lambda i: trainer.step(batches[i % len(batches)], eager=True))
+    if not use_graph:
+        phases = phases_eager
 
     roofline, kernels = None, {}
     if not args.no_roofline:
         # (HIP events per launch cannot be recorded inside a graph replay: the instrumented steps run eagerly)
-        agg, kernels = profile_launches(lambda i: trainer.step(batches[i % len(batches)], eager=True), 3, rank, sync, CH)
+        agg, kernels, launches = profile_launches(lambda i: trainer.step(batches[i % len(batches)], eager=True), 3, rank, sync, CH)
         if rank == 0:
             tag = args.config if not (args.config == "c4" and args.dtype == "bf16") else "c4bf16"
             if args.dtype != "bf16":
-                SPLIT_KERNELS.add("mlp_x6_kernel")
+                SPLIT_KERNELS.update(("mlp_x6_kernel", "x6_program_kernel"))
                 if CH.WGRAD_X6:
                     SPLIT_KERNELS.add("wgrad_kernel")
-            roofline = roofline_of(agg, args.dtype, tag, args.preset and args.model == "attncnp", 3)
+            roofline = roofline_of(agg, args.dtype, tag, args.preset and args.model == "attncnp", 3,
+                                   elapsed / args.steps * 1e3, launches)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -516,10 +571,19 @@ def main_train(args, rank, world, dev, sync, rehearsal):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_spread": spread,
+            "allreduce_ms_exposed": phases.get("allreduce_ms_exposed") if world > 1 else 0.0,
+            "backward_ms": phases.get("backward_ms"),
+            "eager": {"ms_per_step": ms_eager, "backward_ms": phases_eager.get("backward_ms"),
+                      "allreduce_ms_exposed": phases_eager.get("allreduce_ms_exposed") if world > 1 else 0.0,
+                      "note": "the same steps launched eagerly (Trainer(use_graph=False)): bucketed all-reduce overlapped with "
+                              "the backward pass; the headline replays the step from HIP graphs (N > 1: forward + backward "
+                              "graph, ONE all-reduce of the flat gradient, Adam graph)"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32" if os.environ.get("NPF_NO_WGRAD_X6", "0") == "1" and os.environ.get("NPF_NO_MLP_X6", "0") == "1" else
+                      "f32 (every contraction of the step: fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation -- f32 results, DESIGN.md 3.2 / 3.8; the 1-4-wide first / last layers: f32 FMAs)"
+                      if os.environ.get("NPF_NO_X6_FUSED", "0") != "1" and args.attention == "scaledot" and args.model == "attncnp" and args.r == 256 else
                       "f32 (attention / first / last layers: v_mfma_f32_16x16x4_f32; 256-wide MLP layers and weight gradients: fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation)")
             if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",

@@ -26,6 +26,10 @@ from . import _lib as L
 # bench.py sets this to a list to time every launch with HIP events on the launch stream:
 # entries are (kernel, algorithmic flops, start event, end event, algorithmic HBM bytes)
 PROFILE = None
+# tests set this to a list: every chain execution then leaves a record of the tensors it read and wrote -- ("fwd", chain,
+# inputs, saved tensors by (step, role), outputs, bf16) and ("bwd", chain, incoming gradients, buffers by (step, role), wgrad
+# jobs, bf16) -- so that a test can check each step against the kernel's OWN stored inputs (tests/teacher.py)
+TRACE = None
 DEBUG_ABLATE = 0  # development only: chain_kernel ablation bits (tools/microbench.py)
 # tests / tools: 1 = 64-point workgroups, 2 = 128-point (paired) workgroups, 0 = the library's choice
 FORCE_WG = int(os.environ.get("NPF_FORCE_WG", "0"))
@@ -396,7 +400,7 @@ class Program:
         L.check(L.load().npf_chain_run(C.byref(prog), L.stream_ptr()), "npf_chain_run")
 
 
-def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
+def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device, tag: str = "") -> None:
     """jobs: dicts(dZ, A, N, K, dW, db=None, ldw=None, per_task=False, accumulate=False)."""
     if not jobs:
         return
@@ -408,7 +412,7 @@ def run_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device) -> None:
         padded = n_tasks * tiles_of(pts) * 32
         nbytes = sum((j["dZ"].element_size() * pad32(j["N"]) + j["A"].element_size() * pad32(j["K"])) * padded
                      + 4 * j["N"] * j["K"] * (n_tasks if j.get("per_task") else 1) for j in jobs)
-        PROFILE.append(("wgrad_kernel", sum(2 * j["N"] * j["K"] for j in jobs) * n_tasks * pts, ev0, ev1, nbytes))
+        PROFILE.append(("wgrad_kernel", sum(2 * j["N"] * j["K"] for j in jobs) * n_tasks * pts, ev0, ev1, nbytes, tag))
     else:
         _run_wgrad(jobs, n_tasks, pts, device)
 
@@ -916,6 +920,8 @@ class _ChainFn(torch.autograd.Function):
             else:  # pragma: no cover
                 raise AssertionError(k)
         prog.launch()
+        if TRACE is not None:
+            TRACE.append(("fwd", chain, T, dict(saved), tuple(outputs), bf16))
         # A saved tensor that is also an output (a chain ending in a ReLU layer: its output doubles as the mask) goes
         # through save_for_backward: kept in the dict it would close a reference cycle (output -> grad_fn -> ctx -> output)
         # that only the cyclic collector frees -- a point-sized tensor leaked per step until then
@@ -944,6 +950,8 @@ class _ChainFn(torch.autograd.Function):
         pending_vec = []      # (tensor index, PT buffer, F): reduced over points and tasks (LayerNorm gamma / beta)
         jobs = []
         gouts = list(gouts)
+        gouts_in = tuple(gouts)
+        bufs = {}  # (step, role) -> gradient buffer this launch writes (TRACE)
         started = False  # has cur been initialised with a gradient yet
 
         def new_pt(F, internal=False):
@@ -1011,12 +1019,14 @@ class _ChainFn(torch.autograd.Function):
                     # through the mask and W^T (the same wave reads back the addresses it wrote)
                     g_res = new_pt(a["N"])
                     prog.store_pt(g_res, a["N"])
+                    bufs[(i, "g_res")] = g_res
                 if a["relu"]:
                     relu_backward(i, a["N"])
                 need_dz = needs_grad[W] or (b >= 0 and needs_grad[b]) or (add >= 0 and needs_grad[add])
                 if need_dz:
                     dz = new_pt(a["N"], internal=not ((add >= 0 and needs_grad[add]) or (b >= 0 and a["bpt"] and needs_grad[b])))
                     prog.store_pt(dz, a["N"])
+                    bufs[(i, "dz")] = dz
                     if needs_grad[W] or (b >= 0 and needs_grad[b]):
                         dW = torch.empty((a["N"], a["K"]), dtype=torch.float32, device=dev)
                         db = torch.empty((a["N"],), dtype=torch.float32, device=dev) if (b >= 0 and not a["bpt"]) else None
@@ -1048,6 +1058,7 @@ class _ChainFn(torch.autograd.Function):
                 if needs_grad[idx]:
                     buf = new_pt(a["F"])
                     prog.store_pt(buf, a["F"])
+                    bufs[(i, "dz")] = buf
                     if k == "add_pt":
                         grads[idx] = (buf, a["mod"])
                     else:
@@ -1071,6 +1082,7 @@ class _ChainFn(torch.autograd.Function):
                 if needs_grad[vv]:
                     dO = new_pt(a["r"], internal=True)
                     prog.store_pt(dO, a["r"])
+                    bufs[(i, "dz")] = dO
                     dV = torch.empty_like(T[vv])
                     jobs.append(dict(dZ=saved[(i, "in")], A=dO, N=a["C"], K=a["r"], dW=dV, per_task=True))
                     grads[vv] = dV
@@ -1087,6 +1099,7 @@ class _ChainFn(torch.autograd.Function):
                 if needs_grad[kk]:
                     dS = new_pt(a["C"], internal=True)
                     prog.store_pt(dS, a["C"])
+                    bufs[(i, "dz")] = dS
                     dK = torch.empty_like(T[kk])
                     jobs.append(dict(dZ=dS, A=saved[(i, "in")], N=a["C"], K=a["r"], dW=dK, per_task=True))
                     grads[kk] = dK
@@ -1113,14 +1126,18 @@ class _ChainFn(torch.autograd.Function):
                                 and tuple(gj[0].shape) == pt_shape(chain.n_tasks, chain.pts, a["F"])
                                 and not any(g2 is gj for j3, g2 in enumerate(grads) if j3 != j2)):
                             prog.add_pt(gj[0], a["F"])
+                            bufs.setdefault((i, "fan_in"), []).append(gj[0])
                             grads[j2] = None
                     buf = new_pt(a["F"])
                     prog.store_pt(buf, a["F"])
+                    bufs[(i, "dx")] = buf
                     grads[idx] = (buf, a["mod"])
             elif k == "input_rows":
                 pass
         prog.launch()
         run_wgrad(jobs, chain.n_tasks, chain.pts, dev)
+        if TRACE is not None:
+            TRACE.append(("bwd", chain, gouts_in, bufs, list(jobs), ctx.bf16, saved, T))
         from .functional import sum_points_pt  # late import (cycle)
 
         for idx, buf, F, mod in pending_taskvec:

@@ -77,6 +77,10 @@ class BucketedGradReducer:
                 self.bucket_of[i] = b
         self._pending = [0] * len(self.buckets)
         self._works: list = []
+        # True: the hooks only gather (no collective is issued from inside the backward pass) and ``finish`` returns the
+        # LOCAL flat gradient; the caller exchanges it with ``exchange()`` -- what a step replayed from a HIP graph does:
+        # the collective stays outside the captured region
+        self.deferred = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
         self.reset()
 
@@ -99,7 +103,7 @@ class BucketedGradReducer:
         grads = [self.flat.params[i].grad for i in rng]
         torch.cat([g.reshape(-1) for g in grads], out=self.flat.flat_grad[lo:hi])
         self._done[b] = True
-        if self.world > 1:
+        if self.world > 1 and not self.deferred:
             self._works.append(dist.all_reduce(self.flat.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
 
@@ -112,13 +116,20 @@ class BucketedGradReducer:
                     g = self.flat.params[i].grad
                     v = self.flat.grad_view(i)
                     v.zero_() if g is None else v.copy_(g.reshape(-1))
-                if self.world > 1:
+                if self.world > 1 and not self.deferred:
                     lo, hi = self.flat.offsets[rng.start], self.flat.offsets[rng.stop]
                     self._works.append(dist.all_reduce(self.flat.flat_grad[lo:hi], op=dist.ReduceOp.SUM,
                                                        group=self.group, async_op=True))
         for w in self._works:
             w.wait()
+        if self.world > 1 and not self.deferred:
+            self.flat.flat_grad.mul_(1.0 / self.world)
+        return self.flat.flat_grad
+
+    def exchange(self) -> torch.Tensor:
+        """``deferred`` mode: ONE all-reduce (sum) of the whole flat gradient -- 3-5 MB, latency-bound -- then 1/world."""
         if self.world > 1:
+            dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.flat_grad.mul_(1.0 / self.world)
         return self.flat.flat_grad
 

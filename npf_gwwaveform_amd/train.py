@@ -54,15 +54,19 @@ class Trainer:
 
     def __init__(self, model: torch.nn.Module, criterion: torch.nn.Module, lr: float = 1e-3, world: Optional[int] = None,
                  bucket_bytes: int = 2 << 20, use_graph: bool = False):
-        """``use_graph``: capture the whole step (forward, loss, backward, Adam) in a HIP graph after a few
-        eager steps and replay it -- for small models whose step is a string of launch latencies.  Needs
-        fixed batch shapes (a new shape or learning rate re-captures) and a single rank.  The range check of
-        the inputs (base.py:241-247) stays in the step as a device reduction; its verdict is read at the next
-        sync point: call :meth:`check_inputs` (e.g. once per epoch) to get the reference's ValueError."""
+        """``use_graph``: capture the step in a HIP graph after a few eager steps and replay it -- a c2-sized step is
+        launched eagerly in 7.4 ms of host time against 6.7 ms of device time.  One rank: the whole step (forward, loss,
+        backward, Adam) is one graph.  Several ranks: forward + loss + backward + the gather into the flat gradient are one
+        graph, Adam a second one, and between the two replays ONE all-reduce of the flat gradient is issued eagerly (no
+        collective inside a captured region; the exchange is latency-bound -- 3-5 MB -- and is then not hidden behind the
+        backward pass, which costs less than the host time of an eager step at these sizes; ``use_graph=False`` keeps the
+        bucketed all-reduce overlapped with the backward pass).  Needs fixed batch shapes (a new shape or learning rate
+        re-captures).  The range check of the inputs (base.py:241-247) stays in the step as a device reduction; its verdict
+        is read at the next sync point: call :meth:`check_inputs` (e.g. once per epoch) to get the reference's ValueError."""
         self.model, self.criterion = model, criterion
         self.flat = FlatParameters(model.parameters())
         self.reducer = BucketedGradReducer(self.flat, world=world, bucket_bytes=bucket_bytes)
-        self.use_graph = bool(use_graph) and self.flat.flat.is_cuda and self.reducer.world == 1
+        self.use_graph = bool(use_graph) and self.flat.flat.is_cuda
         if self.use_graph and hasattr(getattr(model, "n_z_samples_train", None), "rvs"):
             raise ValueError("use_graph=True freezes the step at capture time, but this model draws a random number of "
                              "latent samples per forward (n_z_samples_train is a random variable)")
@@ -71,7 +75,11 @@ class Trainer:
         self.model.train()
         self.criterion.train()
         self._graph = None
+        self._graph_opt = None
         self._eager_steps = 0
+        # set to a list to time the phases of every eager step with HIP events on the launch stream (bench.py): entries are
+        # (start of backward, end of backward, gradient exchange finished); ``phase_times()`` reads them after a sync
+        self.phase_events = None
         self.sync_replicas()
 
     def sync_replicas(self) -> None:
@@ -132,17 +140,42 @@ class Trainer:
                 self._static = {k: v.clone() for k, v in batch.items()}
                 torch.cuda.synchronize()
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
-                    self._static_loss = self._eager_step(self._static)
+                if self.reducer.world == 1:
+                    with torch.cuda.graph(self._graph):
+                        self._static_loss = self._eager_step(self._static)
+                    self._graph_opt = None
+                else:
+                    self.reducer.deferred = True
+                    try:
+                        with torch.cuda.graph(self._graph):
+                            self._static_loss = self._forward_backward(self._static)
+                    finally:
+                        self.reducer.deferred = False
+                    self._graph_opt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph_opt, pool=self._graph.pool()):
+                        self.opt.step()
             finally:
                 self.model.validate_inputs = was
             self._graph_sig = sig  # (a capture records, it does not execute: this batch runs in the replay below)
         for k, v in batch.items():
             self._static[k].copy_(v)
+        timed = self.phase_events is not None
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         self._graph.replay()
+        if self._graph_opt is not None:
+            if timed:
+                ev[1].record()
+            self.reducer.exchange()
+            if timed:
+                ev[2].record()
+                self.phase_events.append(ev)
+            self._graph_opt.replay()
         return self._static_loss.clone()
 
-    def _eager_step(self, batch: dict) -> torch.Tensor:
+    def _forward_backward(self, batch: dict) -> torch.Tensor:
+        """Forward, loss, backward and the gather of the LOCAL gradients into the flat buffer (``reducer.deferred``)."""
         for p in self.flat.params:
             p.grad = None
         self.reducer.reset()
@@ -150,8 +183,42 @@ class Trainer:
         loss = self.criterion(out, batch["Y_trgt"])
         loss.backward()
         self.flat.flat.grad = self.reducer.finish()
+        return loss.detach()
+
+    def _eager_step(self, batch: dict) -> torch.Tensor:
+        for p in self.flat.params:
+            p.grad = None
+        self.reducer.reset()
+        out = self.model(batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"])
+        loss = self.criterion(out, batch["Y_trgt"])
+        timed = self.phase_events is not None and loss.is_cuda
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+        loss.backward()
+        if timed:
+            ev[1].record()
+        self.flat.flat.grad = self.reducer.finish()
+        if timed:
+            ev[2].record()
+            self.phase_events.append(ev)
         self.opt.step()
         return loss.detach()
+
+    def phase_times(self) -> dict:
+        """Means over the steps recorded in ``phase_events`` (call after a device sync).  Eager steps: ``backward_ms`` = the
+        backward pass on the launch stream (its bucketed all-reduces start inside it, on the collective's own stream);
+        graph steps of several ranks: ``backward_ms`` = the replay of forward + backward, and the exchange is the one
+        all-reduce between the two graphs;
+        ``allreduce_ms_exposed`` = what the launch stream spends behind the backward pass until the averaged gradient is
+        ready (the wait for the collectives still in flight, the gather of late buckets, the 1/world scaling) -- the part of
+        the exchange the backward pass did not hide."""
+        evs = self.phase_events or []
+        if not evs:
+            return {}
+        n = len(evs)
+        return {"backward_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / n,
+                "allreduce_ms_exposed": sum(e[1].elapsed_time(e[2]) for e in evs) / n, "steps_timed": n}
 
     # ---- what the reference gets from skorch callbacks (utils/train.py:203-241) ------------------
     def set_lr_decay(self, decay_lr: float, max_epochs: int) -> None:

@@ -32,6 +32,7 @@ class Program:
         self.n_tasks, self.tiles, self.per_task, self.width = n_tasks, tiles, per_task, width
         self.ops: List[dict] = []
         self.tail = None  # (W [4, F], b [4] or None, rows [points, 4])
+        self.tag = ""     # which side / direction this launch is (bench.py lists the launches of a step by it)
 
     def op(self, **kw) -> "Program":
         self.ops.append(kw)
@@ -115,7 +116,7 @@ class Program:
                                     L.stream_ptr()), "npf_x6_run")
         if CH.PROFILE is not None:
             ev1.record()
-            CH.PROFILE.append(("x6_program_kernel", flops, ev0, ev1, nbytes))
+            CH.PROFILE.append(("x6_program_kernel", flops, ev0, ev1, nbytes, self.tag))
 
 
 def task_images(pt: torch.Tensor, pts: int, row: bool = True, tr: bool = True, width: int = WIDTH):
@@ -245,6 +246,7 @@ class _TargetSideFn(torch.autograd.Function):
         rows = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
         Wo, bo = _pad_out(W_out, b_out)
         prog.tail = (Wo, bo, rows)
+        prog.tag = "target side forward (x-encoder, attention, decoder, output layer)"
         prog.launch()
         ctx.geom = (B, T, tiles, dx, C, float(scale), n_out)
         ctx.spec = spec
@@ -298,6 +300,7 @@ class _TargetSideFn(torch.autograd.Function):
             prog.op(**o)
         dz1 = pt()
         prog.op(mask_bits=bits_h1, store_in=dz1)
+        prog.tag = "target side dgrad (decoder, attention backward, x-encoder)"
         prog.launch()
         # weight / key / value gradients
         jobs, grads = [], []
@@ -326,7 +329,7 @@ class _TargetSideFn(torch.autograd.Function):
             jobs.append(dict(dZ=P, A=dO, N=C, K=WIDTH, dW=dV, per_task=True, ldz=WIDTH))  # (P has 256 features per tile)
         if dK is not None:
             jobs.append(dict(dZ=dS, A=Xt_enc, N=C, K=WIDTH, dW=dK, per_task=True, ldz=WIDTH))
-        CH.run_wgrad(jobs, B, T, dev)
+        CH.run_wgrad(jobs, B, T, dev, tag="target side weight / key / value gradients")
         grads[0] = dW1p[:, :dx].contiguous() if dx != 4 else dW1p
         return (None, dK, dV, None, None, None, *grads)
 
@@ -449,6 +452,7 @@ class _ContextSideFn(torch.autograd.Function):
                 acts.append(o["store_out"])
                 bits.append(o["store_bits"])
             prog.op(**o)
+        prog.tag = "context side forward (x-encoder, XY-encoder)"
         prog.launch()
         ctx.geom = (B, Cn, tiles, dx, dy, h)
         ctx.spec = spec
@@ -522,8 +526,9 @@ class _ContextSideFn(torch.autograd.Function):
             dz1 = pt()
             prog.op(mask_bits=bits_h1, store_in=dz1)
             dW1p = wjob(0, dz1, FN._pack(X4), WIDTH, 4)
+        prog.tag = "context side dgrad (XY-encoder, x-encoder)"
         prog.launch()
-        CH.run_wgrad(jobs, B, Cn, dev)
+        CH.run_wgrad(jobs, B, Cn, dev, tag="context side weight gradients")
         if gR is not None and dy != 4:
             grads[2 * (1 + n_x)] = dWr1[:, :dy].contiguous()
         if (gK is not None or dz_m is not None) and dx != 4:

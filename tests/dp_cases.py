@@ -7,6 +7,9 @@ import torch
 CASES = {
     # the c2 / c4 model at a reduced batch: AttnCNP scaledot r = 256, 4-layer encoder / decoder
     "attncnp_r256": dict(kind="AttnCNP", r=256, L=4, B=4, C=64, T=160, steps=2),
+    # the same through ``Trainer(use_graph=True)``: three eager steps (bucketed, overlapped all-reduce), then forward +
+    # backward replayed from a HIP graph, ONE all-reduce of the flat gradient, Adam replayed from a second graph
+    "attncnp_r256_graph": dict(kind="AttnCNP", r=256, L=4, B=4, C=64, T=160, steps=6, use_graph=True),
     # latent model with the target-side encode (q_zCct) and injected noise, ragged point counts
     "attnlnp_r64": dict(kind="AttnLNP", r=64, L=2, B=6, C=37, T=70, steps=2),
 }

@@ -32,7 +32,7 @@ def main():
     case = make_case(case_name)
     # every rank but 0 starts from DIFFERENT weights: only the broadcast in Trainer.__init__ makes the replicas agree
     model, crit = build(case, seed=0 if rank == 0 else 100 + rank)
-    trainer = Trainer(model, crit, lr=1e-3, world=world)
+    trainer = Trainer(model, crit, lr=1e-3, world=world, use_graph=bool(case.get("use_graph")))
     batch = global_batch(case)
     a, b = shard_range(case["B"], rank, world)
     local = {k: v[:, a:b].contiguous() if k == "eps" else v[a:b].contiguous() for k, v in batch.items()}
@@ -46,6 +46,8 @@ def main():
         losses.append(float(trainer.step(local).item()))
         grads.append(trainer.flat.flat_grad.detach().cpu().clone())
     torch.cuda.synchronize()
+    if case.get("use_graph"):
+        assert trainer._graph is not None and trainer._graph_opt is not None, "the step was not replayed from the two graphs"
     st = trainer.opt.state[trainer.flat.flat]
     torch.save({"rank": rank, "losses": losses, "grads": grads, "weights": trainer.flat.flat.detach().cpu().clone(),
                 "exp_avg": st["exp_avg"].detach().cpu().clone(), "exp_avg_sq": st["exp_avg_sq"].detach().cpu().clone(),

@@ -14,7 +14,14 @@ a gradient tensor by up to a few 1e-3 in relative L2 norm.  Both results are val
 is therefore a full-tensor relative L2 error (outputs 5e-3, gradients 1e-2) plus a max-norm cap of 3e-2, and
 the requirement that the HIP result is closer to the bf16 emulation than to the fp32 oracle (which is 2e-2 ..
 4e-1 away on the gradients): a wrong-but-correlated bf16 backward cannot pass this, a missing rounding
-step shows up as a distance of the fp32-vs-bf16 size."""
+step shows up as a distance of the fp32-vs-bf16 size.
+
+That end-to-end comparison is a SANITY bound.  The gate proper is teacher-forced (tests/teacher.py,
+``test_bf16_mode_teacher_forced`` and inside every end-to-end case): each LINEAR, softmax, attention contraction, dgrad
+step and weight / key / value gradient of the step is recomputed from the tensors the HIP launch itself stored as that
+step's input and compared at fp32-accumulation tolerances (2e-6 of max|ref| per step, 1e-5 for sums over all points) --
+a flipped rounding cannot propagate through such a check, so it has no exception list.  The end-to-end bound may only
+be exceeded when the teacher-forced gate is clean AND the run contains flipped roundings, which the test prints."""
 import numpy as np
 import pytest
 import torch
@@ -26,9 +33,10 @@ from test_hip_sweep import SWEEP, _oracle
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL_OUT_L2, TOL_GRAD_L2, TOL_MAX = 5e-3, 1e-2, 3e-2
-# 8 tasks x 2 latent samples: the latent merge contracts over 16 rows only, one flipped unit there is 1/16 of a
-# row of every upstream gradient (measured 5.5e-2 L2 / 1.4e-1 max-norm with outputs at 1.6e-3)
-LOOSE = {"g2_lnp_both_c1": (1e-1, 2.5e-1)}
+# the end-to-end bound on a gradient tensor when (and only when) the run holds flipped roundings that the test lists and
+# every teacher-forced check is clean: one flipped unit of a contraction over a handful of rows is a visible share of
+# every upstream gradient (8 tasks x 2 latent samples: 5.5e-2 L2 / 1.4e-1 max-norm with outputs at 1.6e-3)
+SANITY_L2, SANITY_MAX = 1e-1, 2.5e-1
 
 
 def _errs(got, ref):
@@ -55,9 +63,18 @@ CASES.update({k: SWEEP[k] for k in ("cnp_r48", "cnp_r100_dx3_dy1", "cnp_r200_L1"
                                     "attncnp_r256_res", "attncnp_xt128_r256")})
 
 
-def _hip_bf16(case, inp, params):
+def _hip_bf16(case, inp, params, trace=None):
     import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd import chain as CH
 
+    CH.TRACE = trace
+    try:
+        return _hip_bf16_run(A, case, inp, params)
+    finally:
+        CH.TRACE = None
+
+
+def _hip_bf16_run(A, case, inp, params):
     model = build_model(case, DEV, params=params)
     dinp = {k: v.to(DEV) for k, v in inp.items()}
     if "eps" in dinp:
@@ -89,10 +106,49 @@ def test_bf16_mode_variants(name):
     _gate(name, case, specs.golden_params(specs.load_golden(name)), specs.make_inputs(case, seed=4321))
 
 
+def _teacher_forced(trace, name):
+    """The gate proper: every step of every chain launch against the launch's own stored inputs (tests/teacher.py)."""
+    import teacher
+
+    rep = teacher.check_trace(trace)
+    bad = rep.failures()
+    assert rep.rows and not bad, f"{name}: teacher-forced checks failed:\n" + "\n".join(f"  {w}: {e:.3e} > {t:.0e}" for w, e, t in bad[:20])
+    print(f"{name}: {rep.summary()}")
+    return rep
+
+
+@pytest.mark.parametrize("name", ["g3_attncnp_c2", "g4_attnlnp_c2", "stress_case_70"])
+def test_bf16_mode_teacher_forced(name):
+    """BASELINE config 3's models at batch 2 (AttnCNP, AttnLNP with the target-side latent encode) and the randomised
+    sweep's case 70 (CNP, r = 256, residual layers, 2 tasks -- the case whose ``loc`` landed at 5.5e-3 against the 5e-3 of
+    the end-to-end bound in round 2): every layer's output, dX and dW from the HIP path's own stored inputs."""
+    if name == "stress_case_70":
+        import random
+
+        from test_hip_stress import _random_case
+
+        rng = random.Random(0)
+        for _ in range(71):
+            case = _random_case(rng)
+        assert case["kind"] == "CNP" and case["r"] == 256 and case.get("is_res"), case
+        params, inp = specs.make_params(case, seed=170), specs.make_inputs(case, seed=270)
+    else:
+        case = specs.CASES[name]
+        params, inp = specs.make_params(case, seed=11), specs.make_inputs(case, seed=4321)
+    trace = []
+    _hip_bf16(case, inp, params, trace=trace)
+    rep = _teacher_forced(trace, name)
+    assert any(rec[5] for rec in trace), "no chain ran on the bf16 instance"
+    for f in rep.flips:
+        print("  flip:", f)
+
+
 def _gate(name, case, params, inp):
     ref_p, ref_out, ref_loss = _oracle(case, inp, params, mode="bf16")
     fp_p, fp_out, _ = _oracle(case, inp, params, mode="fp32")
-    model, out, loss = _hip_bf16(case, inp, params)
+    trace = []
+    model, out, loss = _hip_bf16(case, inp, params, trace=trace)
+    rep = _teacher_forced(trace, name)
 
     _check(out[0].base_dist.loc, ref_out["loc"], TOL_OUT_L2, TOL_MAX, "loc")
     _check(out[0].base_dist.scale, ref_out["scale"], TOL_OUT_L2, TOL_MAX, "scale")
@@ -101,21 +157,32 @@ def _gate(name, case, params, inp):
         _check(out[1], ref_out["z_samples"], TOL_OUT_L2, TOL_MAX, "z_samples")
         _check(out[2].base_dist.loc, ref_out["q_zCc"][0], TOL_OUT_L2, TOL_MAX, "q_zCc.loc")
         _check(out[2].base_dist.scale, ref_out["q_zCc"][1], TOL_OUT_L2, TOL_MAX, "q_zCc.scale")
-    tol_l2, tol_max = LOOSE.get(name, (TOL_GRAD_L2, TOL_MAX))
     worst = worst32 = 0.0
+    over = []
     for k, p in model.named_parameters():
         ref = ref_p[k].grad if ref_p[k].grad is not None else torch.zeros_like(ref_p[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         if float(ref.abs().max()) == 0.0:
             assert float(got.abs().max()) == 0.0, k
             continue
-        worst = max(worst, _check(got, ref, tol_l2, tol_max, f"grad {k}"))
+        l2, mx = _errs(got, ref)
+        if l2 > TOL_GRAD_L2 or mx > TOL_MAX:
+            over.append((k, l2, mx))
+            _check(got, ref, SANITY_L2, SANITY_MAX, f"grad {k}")
+        worst = max(worst, l2)
         if fp_p[k].grad is not None:
             worst32 = max(worst32, _errs(got, fp_p[k].grad)[0])
+    if over:
+        # beyond the end-to-end bound: only with flipped roundings on record (the teacher-forced gate above was clean)
+        assert rep.n_flips > 0, f"{name}: gradients beyond the end-to-end bound without a flipped rounding: {over}"
+        print(f"{name}: {len(over)} gradient tensor(s) beyond the end-to-end bound ({TOL_GRAD_L2:.0e} L2 / {TOL_MAX:.0e} max), "
+              f"worst {max(o[1] for o in over):.2e} L2; {rep.n_flips} flipped roundings in the run, e.g.")
+        for f in rep.flips[:6]:
+            print("  flip:", f)
     # the bf16 instances really ran, and the emulation -- not the fp32 oracle -- is what they compute
     l2_16, l2_32 = _errs(out[0].base_dist.loc, ref_out["loc"])[0], _errs(out[0].base_dist.loc, fp_out["loc"])[0]
     assert l2_32 > 1e-4 and l2_16 < 0.6 * l2_32, (l2_16, l2_32)
-    if name not in LOOSE:
+    if not over:
         assert worst < 0.6 * worst32, (worst, worst32)
     print(f"{name}: loc rel L2 {l2_16:.1e} (fp32 oracle: {l2_32:.1e}); worst gradient rel L2 {worst:.1e} (fp32 oracle: {worst32:.1e})")
 

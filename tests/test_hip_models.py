@@ -294,8 +294,10 @@ def _c2_model_and_batch(B, seed=7):
     return model, synthetic_waveform_batch(B, case["C"], case["T"], seed, DEV)
 
 
-def test_full_size_config2_properties():
-    """Size-independent properties at BASELINE config 2's full size (256 tasks x 1024 targets), where
+@pytest.mark.parametrize("B", [256, 1024], ids=["c2_256_tasks", "c4_1024_tasks_per_rank"])
+def test_full_size_config2_properties(B):
+    """Size-independent properties at BASELINE config 2's full size (256 tasks x 1024 targets) and at config 4's per-rank
+    size (1024 tasks x 1024 targets, fp32: what one of the 8 ranks of the data-parallel run computes), where
     the CPU oracle is too slow to be the checker:
       * tasks are independent (base.py:177-239 has no cross-task op before the loss mean): a task
         evaluated alone gives the same loc / sigma as inside the full batch;
@@ -304,13 +306,12 @@ def test_full_size_config2_properties():
       * the gradient of the batch-mean loss is the mean of the two half-batch gradients."""
     import npf_gwwaveform_amd as A
 
-    B = 256
     model, batch = _c2_model_and_batch(B)
     crit = A.CNPFLoss()
     p = model(batch["X_cntxt"], batch["Y_cntxt"], batch["X_trgt"], batch["Y_trgt"])[0]
     loc, scale = p.base_dist.loc.detach(), p.base_dist.scale.detach()
     assert torch.isfinite(loc).all() and torch.isfinite(scale).all() and (scale >= 0.01).all()
-    for i in (0, 101, 255):
+    for i in (0, 101, B - 1):
         one = {k: v[i:i + 1] for k, v in batch.items()}
         pi = model(one["X_cntxt"], one["Y_cntxt"], one["X_trgt"], one["Y_trgt"])[0]
         assert_close(pi.base_dist.loc, loc[:, i:i + 1], tol=1e-6, what=f"task {i} alone: loc")

@@ -33,13 +33,75 @@ def kname(raw: str) -> str:
     return n.strip()
 
 
+def _grid(row) -> int:
+    for key in ("Grid_Size", "Grid_Size_X", "grid_size", "Grid_Size_x"):
+        if key in row and row[key] not in ("", None):
+            return int(float(row[key]))
+    return 0
+
+
+# x6 programs: one kernel, four launches per train step (npf_gwwaveform_amd/x6.py).  The two target-side launches -- the ones
+# that hold the scaled-dot attention -- have the larger grid; within a side the launches alternate forward, dgrad.
+X6 = "npf::x6_program_kernel"
+
+
+class _X6Rows:
+    """Names the dispatches of the x6 program kernel by side (grid size) and direction (order of appearance)."""
+
+    def __init__(self):
+        self.seen = collections.Counter()
+        self.ids = {}
+
+    def feed(self, rows):
+        rows = [r for r in rows if kname(r.get("Kernel_Name", r.get("Name", ""))) == X6]
+        if not rows:
+            return
+        big = max(_grid(r) for r in rows)
+        for r in sorted(rows, key=lambda r: int(r.get("Dispatch_Id", 0))):
+            did = int(r.get("Dispatch_Id", 0))
+            if did in self.ids:
+                continue
+            side = "target side (attention inside)" if _grid(r) == big else "context side"
+            n = self.seen[side]
+            self.seen[side] += 1
+            self.ids[did] = f"{X6} [{side}, {'forward' if n % 2 == 0 else 'dgrad'}]"
+
+    def name(self, row):
+        return self.ids.get(int(row.get("Dispatch_Id", -1)))
+
+
 def counters(d):
+    """kernel -> counter -> values per dispatch; x6 program dispatches additionally under their per-launch row names."""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     f = find(d, "*counter_collection.csv")
     if not f:
         return out
-    for row in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    x6 = _X6Rows()
+    # (a dispatch has one row per counter: classify on one counter's rows only)
+    first = rows[0]["Counter_Name"] if rows else None
+    x6.feed([r for r in rows if r["Counter_Name"] == first])
+    for row in rows:
         out[kname(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        sub = x6.name(row)
+        if sub:
+            out[sub][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return out
+
+
+def trace_rows(d):
+    """Per-launch rows of the x6 program kernel from the kernel trace of the stats pass: name -> [durations in ns]."""
+    out = collections.defaultdict(list)
+    f = find(d, "*kernel_trace.csv")
+    if not f:
+        return out
+    rows = list(csv.DictReader(open(f)))
+    x6 = _X6Rows()
+    x6.feed(rows)
+    for r in rows:
+        sub = x6.name(r)
+        if sub:
+            out[sub].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return out
 
 
@@ -59,6 +121,9 @@ def main():
                 k["total_ns"] += float(row["TotalDurationNs"])
                 k["pct"] += float(row["Percentage"])
                 k["avg_ns"] = k["total_ns"] / k["calls"]
+    for sub, durs in trace_rows(os.path.join(src, "stats")).items():
+        summary["kernels"][sub] = {"calls": len(durs), "total_ns": sum(durs), "avg_ns": sum(durs) / len(durs),
+                                   "row_of": X6}
     fetch, write, mfma = (counters(os.path.join(src, k)) for k in ("fetch", "write", "mfma"))
     for name in list(summary["kernels"]):
         k = summary["kernels"][name]
