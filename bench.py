@@ -465,6 +465,7 @@ def main_decode(args, rank, world, dev, sync):
     if not args.no_roofline:
         agg, kernels, launches = profile_launches(step, 2, rank, sync, CH)
         if rank == 0:
+            SPLIT_KERNELS.update(("mlp_x6_kernel", "x6_program_kernel"))
             roofline = roofline_of(agg, "fp32", "c5", args.preset, 2, elapsed / args.steps * 1e3, launches)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -475,7 +476,10 @@ def main_decode(args, rank, world, dev, sync):
             "metric": "waveform target-points/sec (decode only)", "value": value, "unit": "target-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_spread": spread,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation "
+                      "-- f32 results, DESIGN.md 3.2 / 3.8)" if "x6_program_kernel" in kernels else "f32"),
+            "data": "synthetic",
             "config": {"workload": f"BASELINE config 5: decode(X_trgt_enc, R_trgt) only, {r}-wide {L}-layer decoder, {T} target "
                                    f"points per waveform, {B} waveforms per GPU, fp32, encoder outputs resident in HBM "
                                    f"(row-major [B,T,r] as the reference's decode takes them)",

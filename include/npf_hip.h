@@ -380,11 +380,24 @@ typedef struct npf_x6_op {
   int32_t softmax_n;   /* 0 = no softmax */
   float softmax_scale;
   float sbwd_scale;
-  int32_t reserved[2];
+  int32_t reserved[2]; /* [0]: NPF_X6_IN_RM | NPF_X6_ADD_RM; [1]: 0 */
 } npf_x6_op_t;
+/* op flags (reserved[0]): in_pt / addend are ROW-MAJOR [n_tasks][pts_per_task][F] tensors -- what the reference's decode(X_trgt_enc,
+ * R_trgt) is handed (npf/neuralproc/base.py:327) -- read without a layout pass (inference inputs: no gradient flows into them) */
+#define NPF_X6_IN_RM 1
+#define NPF_X6_ADD_RM 2
+/* 256-feature programs, the library's choice of points per wave (npf_x6_run_ex variant 0): 1 = 16 points (two workgroups per CU),
+ * 2 = 32 points (one wave per SIMD, every weight fragment feeds twice the matrix instructions) */
+#define NPF_X6_DEFAULT_VARIANT 1
 /* out_rows != NULL: a F -> 4 layer behind the program, out_rows[point][n] = sum_f out_w[n][f] cur[f] + out_b[n] (the decoder's
  * output layer, mlp.py:109).  per_task != 0: every workgroup stays inside one task (required by per-task weights / biases).
  * width: 128 or 256. */
+/* npf_x6_run_ex: the same with pts_per_task valid points per task (<= 32 tiles_per_task; row-major operands are indexed with it),
+ * width 128, 256 or 512 (512: no ReLU-bit operands -- inference programs, e.g. the r = 512 decoder of base.py:327-367 from
+ * row-major inputs), and variant = 0 (library's choice) | 1 | 2 (NPF_X6_DEFAULT_VARIANT above; 2 needs width 256). */
+int npf_x6_run_ex(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const float *out_b, float *out_rows,
+                  int32_t n_tasks, int32_t tiles_per_task, int32_t pts_per_task, int32_t per_task, int32_t width,
+                  int32_t variant, void *stream);
 int npf_x6_run(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const float *out_b, float *out_rows,
                int32_t n_tasks, int32_t tiles_per_task, int32_t per_task, int32_t width, void *stream);
 /* The three-term images of a PT32 tensor src [n_tasks][tiles_per_task][F/4][32][4] taken as per-task weights, F = width:

@@ -73,6 +73,7 @@ class NpfX6Layer(C.Structure):
 
 
 NPF_X6_MAX_OPS = 12
+X6_IN_RM, X6_ADD_RM = 1, 2  # npf_x6_op_t.reserved[0]: in_pt / addend are row-major [n_tasks][pts][F] tensors
 
 
 class NpfX6Op(C.Structure):
@@ -110,6 +111,7 @@ SIGNATURES = {
     "npf_mlp_x6_run": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _i32, _i32, _p]),
     "npf_mlp_x6_run_rows": (C.c_int, [C.POINTER(NpfX6Layer), _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
     "npf_x6_run": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "npf_x6_run_ex": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "npf_x6_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "npf_version": (C.c_int, []),
 }

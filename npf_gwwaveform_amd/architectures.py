@@ -348,6 +348,14 @@ class MergeFlatInputs(nn.Module):
         d2 = x2.shape[-1]
         no_grad = not torch.is_grad_enabled() or not (x1.requires_grad or x2.requires_grad or
                                                       any(p.requires_grad for p in self.parameters()))
+        if self.is_sum_merge and no_grad and n1 == n2 and n_out <= 4:
+            from . import x6
+
+            x1r, x2r = x1.reshape(n1, T, d1), x2.reshape(n2, T, d2)
+            if x6.decode_rows_usable(self, x1r, x2r):
+                # inference at a width the x6 programs cover (128 / 256 / 512): merge, decoder and output layer as ONE launch on
+                # the bf16 matrix pipe (fp32 results), straight from the row-major tensors
+                return x6.decode_rows(self, x1r, x2r).reshape(*lead2, T, n_out)
         if self.is_sum_merge and no_grad and d1 % 32 == 0 and d2 % 32 == 0:
             # inference: the row-major module-boundary tensors go straight into the chain (no PT32
             # packing pass over x1 and x2)

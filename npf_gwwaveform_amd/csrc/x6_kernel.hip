@@ -19,6 +19,11 @@
 // wavefront shuffles (ds_bpermute), fp32 with max subtraction like torch.softmax.
 #include "npf_common.hpp"
 
+// Timing-only diagnostic builds (tools/fastbuild.sh x6_kernel OUT.so -DXP_NO_...): each removes one ingredient of the slab
+// loop, results are garbage, only the clock counts.  None is defined in the library build.
+//   XP_NO_MFMA  no matrix instructions      XP_NO_FRAG  no weight-fragment reads from LDS     XP_NO_DMA  no slab DMA
+//   XP_NO_STORE no global stores of the ops XP_NO_SPLIT the layer input is not split (bits reinterpreted)
+
 namespace npf {
 
 typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
@@ -33,8 +38,9 @@ struct XpArgs {
   float* out_rows;
   int32_t n_ops, n_mm;
   int32_t total_tiles, tiles_per_task;
-  int32_t wgs_per_task;  // 0: tiles dealt flat, two per workgroup
+  int32_t wgs_per_task;  // 0: tiles dealt flat (two or four per workgroup)
   int32_t xcd_remap;     // the workgroups of a task on one XCD (grid a multiple of 8)
+  int32_t pts_per_task;  // valid points per task (row-major operands; PT32 operands are padded to whole tiles)
 };
 
 template <int KF>
@@ -64,6 +70,12 @@ __device__ __forceinline__ unsigned xp_cvt_pk(float a, float b) {
 
 // (see x6m_split in mlp_x6_kernel.hip for the edge-value semantics)
 __device__ __forceinline__ void xp_split(const f32x4& lo, const f32x4& hi, xp_u32x4& t0, xp_u32x4& t1, xp_u32x4& t2) {
+#ifdef XP_NO_SPLIT
+  t0 = __builtin_bit_cast(xp_u32x4, lo);
+  t1 = __builtin_bit_cast(xp_u32x4, hi);
+  t2 = t0 ^ t1;
+  return;
+#endif
   const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -90,54 +102,90 @@ __device__ __forceinline__ float xp_max4(float v) {
   return v;
 }
 
-template <int KF>
-__global__ __launch_bounds__(256, 2) void x6_program_kernel(const XpArgs a) {
+// NPG = 16-point groups per wave.  <256, 1> / <128, 1>: a wave owns half a tile, 216-256 registers, two workgroups per CU.
+// <256, 2>: a wave owns a whole tile -- every weight fragment read from LDS and every slab piece streamed from L2 feeds twice the
+// matrix instructions -- and <512, 1>: 512 features of 16 points; both keep 320 registers of activation terms and run one wave
+// per SIMD (512 registers).
+template <int KF, int NPG>
+__global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_kernel(const XpArgs a) {
   using G = XpGeom<KF>;
   constexpr int NB = G::NB, KS = G::KS;
+  constexpr int TPW = NPG == 2 ? 4 : 2;  // tiles per workgroup
+  static_assert(NPG == 1 || NPG == 2, "a wave owns half a tile or a whole one");
   __shared__ __attribute__((aligned(16))) char smem[G::Slots * G::SlabB + G::BiasB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
   int bid = blockIdx.x;
   if (a.xcd_remap) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-  int task = 0;
-  long tile;
+  const int w_tile = NPG == 2 ? wave : (wave >> 1);  // this wave's tile inside the workgroup
+  const int half0 = NPG == 2 ? 0 : (wave & 1);       // its first half tile
+  int task, t_in;
   bool valid;
   if (a.wgs_per_task > 0) {
     task = bid / a.wgs_per_task;
-    const int t_in = (bid - task * a.wgs_per_task) * 2 + (wave >> 1);
+    t_in = (bid - task * a.wgs_per_task) * TPW + w_tile;
     valid = t_in < a.tiles_per_task;
-    tile = (long)task * a.tiles_per_task + t_in;
   } else {
-    tile = (long)bid * 2 + (wave >> 1);
-    valid = tile < a.total_tiles;
+    const long t = (long)bid * TPW + w_tile;
+    valid = t < a.total_tiles;
+    task = valid ? (int)(t / a.tiles_per_task) : 0;
+    t_in = valid ? (int)(t - (long)task * a.tiles_per_task) : 0;
   }
-  if (!valid) tile = 0;  // (a wave without a tile still streams slabs and meets barriers; it loads tile 0 and stores nothing)
-  // this lane's float4 column in its tile of a PT32 tensor with KF features: block b at + (4 b + g) * 128 floats
-  const size_t lane_off = (size_t)tile * (KF * 32) + (size_t)(16 * (wave & 1) + p) * 4 + (size_t)g * 128;
-  const size_t bits_off = ((size_t)tile * 2 + (wave & 1)) * 64 + lane;  // [tile][half][64 lanes] uint64
-  const size_t row_idx = (size_t)tile * 32 + 16 * (wave & 1) + p;       // this lane's point in a rows tensor
+#ifdef XP_NO_STORE
+  valid = valid && a.n_ops > 1000;  // (never true: the stores stay in the code, none executes)
+#endif
+  // (a wave without a tile still streams slabs and meets barriers; it loads tile 0 and stores nothing)
+  const long tile = valid ? (long)task * a.tiles_per_task + t_in : 0;
+  if (a.wgs_per_task == 0) task = 0;  // (flat launches share every weight: no per-task strides)
+  // this lane's float4 column in its tile of a PT32 tensor with KF features: block b at + (4 b + g) * 128 floats; the second
+  // point group of a wave (NPG == 2) 16 points = 64 floats further
+  // Addresses = a wave-uniform part (scalar registers) + a 32-bit lane part: nothing 64-bit per lane stays live across the slab
+  // loops (per-slab store addresses kept in vector registers were what hipcc spilled inside the loop).
+  const size_t tile_off = (size_t)tile * (KF * 32);                       // floats, wave-uniform
+  const unsigned lane_b = (unsigned)(((16 * half0 + p) * 4 + g * 128) * 4);  // bytes inside the tile
+  const size_t bits_off = ((size_t)tile * 2 + half0) * 64;                // [tile][half][64 lanes] uint64, + lane
+  const size_t row_off = (size_t)tile * 32 + 16 * half0;                  // a rows tensor: + p
+  // PT32 operand ``base``: the float4 of block b of this lane's point in point group pg
+  auto pt32 = [&](const float* base, int pg, int b) -> f32x4* {
+    return (f32x4*)((char*)const_cast<float*>(base + tile_off + (size_t)(b * 512 + 64 * pg)) + lane_b);
+  };
+  // row-major operands [task][pts][KF] (NPF_X6_IN_RM / NPF_X6_ADD_RM): this lane's point, clamped into the task (padding points of
+  // the last tile re-read its last point: loaded, never stored)
+  auto rm32 = [&](const float* base, int pg, int b) -> const f32x4* {
+    int pt = (valid ? t_in : 0) * 32 + 16 * (half0 + pg) + p;
+    pt = pt < a.pts_per_task ? pt : a.pts_per_task - 1;
+    const size_t tk = valid ? (size_t)(tile / a.tiles_per_task) : 0;
+    return (const f32x4*)(base + (tk * a.pts_per_task + (size_t)pt) * KF + 4 * g + 16 * b);
+  };
 
   // DMA of a slab: 3 * PPT pieces of 1 KiB (term q / PPT, rows RPP (q % PPT) ..), NP per wave; the swizzle (chunk c of row r at
   // position c ^ (r & 15)) is applied to the source address: uniform base per piece + a lane offset
   constexpr int LPR = 64 / G::RPP;  // lanes per row of a piece
-  unsigned dma_lane[2];
+  constexpr int NDL = G::PPT / 4 > 0 ? G::PPT / 4 : 1;  // distinct first rows of a wave's pieces
+  unsigned dma_lane[NDL];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NDL; ++n) {
     const int r0 = G::RPP * ((wave + 4 * n) % G::PPT), row = r0 + lane / LPR, pos = lane % LPR;
     dma_lane[n] = (unsigned)((lane / LPR) * G::RowB + ((pos ^ (row & 15)) << 4));
   }
   const int n_slabs = a.n_mm * NB;
-  auto dma_slab = [&](int S, char* slot) {
-    const int j = S / NB;
-    const char* base = a.mm_img[j] + (size_t)task * a.mm_stride[j] + (size_t)(S % NB) * 16 * G::RowB;
+  // piece n of this wave's share of a slab (term q / PPT, rows RPP (q % PPT) .., q = wave + 4 n); ``rows`` = the slab's first row
+  // inside its multiply's image ``img`` (wave-uniform)
+  auto dma_piece = [&](const char* img, int rows, char* slot, int n) {
+#ifdef XP_NO_DMA
+    return;
+#endif
+    const char* base = img + (size_t)rows * G::RowB;
     asm volatile("" : "+s"(base));
+    const int q = wave + 4 * n, term = q / G::PPT, r0 = G::RPP * (q % G::PPT);
+    xp_dma16(base + (size_t)term * ((size_t)KF * KF * 2) + r0 * G::RowB + dma_lane[n % NDL], slot + term * G::TermB + r0 * G::RowB);
+  };
+  auto mm_base = [&](int j) { return a.mm_img[j] + (size_t)task * a.mm_stride[j]; };
+  auto dma_slab = [&](int S, char* slot) {
+    const char* img = mm_base(S / NB);
 #pragma unroll
-    for (int n = 0; n < G::NP; ++n) {
-      const int q = wave + 4 * n, term = q / G::PPT, r0 = G::RPP * (q % G::PPT);
-      xp_dma16(base + (size_t)term * (KF * KF * 2) + r0 * G::RowB + dma_lane[(G::PPT == 8) ? (n & 1) : 0],
-               slot + term * G::TermB + r0 * G::RowB);
-    }
+    for (int n = 0; n < G::NP; ++n) dma_piece(img, (S % NB) * 16, slot, n);
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lane_row = (unsigned)(p * G::RowB);
@@ -146,116 +194,148 @@ __global__ __launch_bounds__(256, 2) void x6_program_kernel(const XpArgs a) {
   if (n_slabs > 0) dma_slab(0, smem);
   if (n_slabs > 1) dma_slab(1, smem + G::SlabB);
   int slot = 0, S0 = 0, jm = 0;  // ring slot of the next slab, its number, the multiply it belongs to
-  f32x4 cur[NB];
+  f32x4 cur[NPG][NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) cur[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int pg = 0; pg < NPG; ++pg)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cur[pg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int l = 0; l < a.n_ops; ++l) {
     const npf_x6_op_t& o = a.op[l];
+    const int oflags = o.reserved[0];
     // ---------------------------------------------------------------- input side
-    if (o.in_pt != nullptr) {
-      const float* x = o.in_pt + lane_off;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) cur[b] = *(const f32x4*)(x + b * 512);
-    }
-    if (o.in_rows != nullptr) {
-      // cur <- [relu](in_w^T rows + in_b): the first layer of an MLP whose input has <= 4 features (mlp.py:96), or the dgrad
-      // of an F -> 4 output layer (mlp.py:109): plain fp32 FMAs, the matrix from L1 / L2
-      const f32x4 r = ((const f32x4*)o.in_rows)[row_idx];
-      const int nb_in = o.in_n >> 4;
+    for (int pg = 0; pg < NPG; ++pg) {
+      if (o.in_pt != nullptr) {
+        if (oflags & NPF_X6_IN_RM) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b < nb_in) {
-          const int f = 16 * b + 4 * g;
-          if (o.in_b != nullptr) v = *(const f32x4*)(o.in_b + f);
+          for (int b = 0; b < NB; ++b) cur[pg][b] = *rm32(o.in_pt, pg, b);
+        } else {
 #pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const f32x4 w = *(const f32x4*)(o.in_w + (size_t)n * o.in_n + f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(r[n], w[e], v[e]);
-          }
-          if (o.in_relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
+          for (int b = 0; b < NB; ++b) cur[pg][b] = *pt32(o.in_pt, pg, b);
         }
-        cur[b] = v;
       }
-    }
-    if (o.pre_add != nullptr) {
-      const float* x = o.pre_add + lane_off;
+      if (o.in_rows != nullptr) {
+        // cur <- [relu](in_w^T rows + in_b): the first layer of an MLP whose input has <= 4 features (mlp.py:96), or the dgrad
+        // of an F -> 4 output layer (mlp.py:109): plain fp32 FMAs, the matrix from L1 / L2
+        const f32x4 r = ((const f32x4*)o.in_rows)[row_off + 16 * pg + p];
+        const int nb_in = o.in_n >> 4;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) cur[b] += *(const f32x4*)(x + b * 512);
-    }
-    if (o.mask != nullptr) {
-      const float* m = o.mask + lane_off;
+        for (int b = 0; b < NB; ++b) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (b < nb_in) {
+            const int f = 16 * b + 4 * g;
+            if (o.in_b != nullptr) v = *(const f32x4*)(o.in_b + f);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const f32x4 v = *(const f32x4*)(m + b * 512);
+            for (int n = 0; n < 4; ++n) {
+              const f32x4 w = *(const f32x4*)(o.in_w + (size_t)n * o.in_n + f);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cur[b][e] = v[e] > 0.f ? cur[b][e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = fmaf(r[n], w[e], v[e]);
+            }
+            if (o.in_relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+          }
+          cur[pg][b] = v;
+        }
       }
-    }
-    if (o.mask_bits != nullptr) {
-      const unsigned long long w = o.mask_bits[bits_off];
+      if (o.pre_add != nullptr) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cur[b][e] = ((w >> (4 * b + e)) & 1ull) ? cur[b][e] : 0.f;
-    }
-    if (o.sbwd_p != nullptr) {
-      // softmax backward (the autograd of attention.py:161): dS = scale * P * (dP - sum_c dP_c P_c)
-      const float* pp = o.sbwd_p + lane_off;
-      f32x4 P[NB];
-      float dot = 0.f;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        P[b] = *(const f32x4*)(pp + b * 512);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dot = fmaf(cur[b][e], P[b][e], dot);
+        for (int b = 0; b < NB; ++b) cur[pg][b] += *pt32(o.pre_add, pg, b);
       }
-      dot = xp_sum4(dot);
+      if (o.mask != nullptr) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b) {
+          const f32x4 v = *pt32(o.mask, pg, b);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cur[b][e] = o.sbwd_scale * P[b][e] * (cur[b][e] - dot);
-    }
-    if (o.store_in != nullptr && valid) {
-      float* d = o.store_in + lane_off;
+          for (int e = 0; e < 4; ++e) cur[pg][b][e] = v[e] > 0.f ? cur[pg][b][e] : 0.f;
+        }
+      }
+      if constexpr (NB <= 16) {
+        if (o.mask_bits != nullptr) {
+          // one sign-extended bit-field extract + one AND per value (bit 4 b + e of the lane's 64-bit word)
+          const unsigned long long w = o.mask_bits[bits_off + 64 * pg + lane];
+          const int wl = (int)(unsigned)w, wh = (int)(unsigned)(w >> 32);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) __builtin_nontemporal_store(cur[b], (f32x4*)(d + b * 512));
-    }
-    if (o.store_in_bits != nullptr && valid) {
-      unsigned long long w = 0ull;
+          for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+            for (int e = 0; e < 4; ++e) {
+              // (through scalar temporaries: __builtin_bit_cast applied to an element of an ext_vector read element 0, hipcc 7.2)
+              const int m = __builtin_amdgcn_sbfe(b < 8 ? wl : wh, 4 * (b & 7) + e, 1);
+              const float x = cur[pg][b][e];
+              cur[pg][b][e] = __int_as_float(__float_as_int(x) & m);
+            }
+        }
+      }
+      if constexpr (NB <= 16) if (o.sbwd_p != nullptr) {
+        // softmax backward (the autograd of attention.py:161): dS = scale * P * (dP - sum_c dP_c P_c)
+        f32x4 P[NB];
+        float dot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w |= (unsigned long long)(cur[b][e] > 0.f) << (4 * b + e);
-      o.store_in_bits[bits_off] = w;
+        for (int b = 0; b < NB; ++b) {
+          P[b] = *pt32(o.sbwd_p, pg, b);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dot = fmaf(cur[pg][b][e], P[b][e], dot);
+        }
+        dot = xp_sum4(dot);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cur[pg][b][e] = o.sbwd_scale * P[b][e] * (cur[pg][b][e] - dot);
+      }
+      if (o.store_in != nullptr && valid) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) __builtin_nontemporal_store(cur[pg][b], pt32(o.store_in, pg, b));
+      }
+      if constexpr (NB <= 16) {
+        if (o.store_in_bits != nullptr && valid) {
+          unsigned wlo = 0u, whi = 0u;
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) (b < 8 ? wlo : whi) |= (unsigned)(cur[pg][b][e] > 0.f) << (4 * (b & 7) + e);
+          o.store_in_bits[bits_off + 64 * pg + lane] = ((unsigned long long)whi << 32) | wlo;
+        }
+      }
     }
     if (o.w_img == nullptr) continue;
 
     // ---------------------------------------------------------------- the multiply
     // the bias into LDS (read back per slab; visible behind the barrier of the op's first slab)
-    if (tid < KF) bias_lds[(jm & 1) * KF + tid] = o.bias != nullptr ? o.bias[(size_t)task * o.bias_task_stride + tid] : 0.f;
+    for (int i = tid; i < KF; i += 256)
+      bias_lds[(jm & 1) * KF + i] = o.bias != nullptr ? o.bias[(size_t)task * o.bias_task_stride + i] : 0.f;
     // the input as three packed bf16 terms (the B operands), once per op
-    xp_u32x4 tb[3][KS];
+    xp_u32x4 tb[NPG][3][KS];
 #pragma unroll
-    for (int st = 0; st < KS; ++st) xp_split(cur[2 * st], cur[2 * st + 1], tb[0][st], tb[1][st], tb[2][st]);
+    for (int pg = 0; pg < NPG; ++pg)
+#pragma unroll
+      for (int st = 0; st < KS; ++st) xp_split(cur[pg][2 * st], cur[pg][2 * st + 1], tb[pg][0][st], tb[pg][1][st], tb[pg][2][st]);
     // an addend (MergeFlatInputs: relu(x1 + resizer(x2)), encoders.py:178-179; a gradient fan-in) waits in the registers of the
     // blocks it will be added to: the input is dead once it is split, and block s is only rewritten at slab s
     const bool has_add = o.addend != nullptr;
     if (has_add) {
-      const float* ad = o.addend + lane_off;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) cur[b] = *(const f32x4*)(ad + b * 512);
+      for (int pg = 0; pg < NPG; ++pg) {
+        if (oflags & NPF_X6_ADD_RM) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) cur[pg][b] = *rm32(o.addend, pg, b);
+        } else {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) cur[pg][b] = *pt32(o.addend, pg, b);
+        }
+      }
     }
-    const bool post = o.softmax_n > 0;  // (the stores then follow the softmax)
-    float* out = (o.store_out != nullptr && valid && !post) ? o.store_out + lane_off : nullptr;
+    // the images the slab stream reads during this multiply: its own, and -- for the last two slabs' prefetch -- the next one's
+    const char* const img0 = mm_base(jm);
+    const char* const img1 = mm_base(jm + 1 < a.n_mm ? jm + 1 : jm);
+    const bool post = NB <= 16 && o.softmax_n > 0;  // (the stores then follow the softmax; 512-wide programs have none)
+    const float* const out = (o.store_out != nullptr && valid && !post) ? o.store_out : nullptr;  // (wave-uniform)
     const unsigned bias_l = lds0 + G::Slots * G::SlabB + (jm & 1) * (KF * 4) + g * 16;
     const bool relu = o.relu != 0;
-    unsigned long long pos_bits = 0ull;
+    unsigned pos_lo[NPG], pos_hi[NPG];  // the output's ReLU bits: blocks 0-7, 8-15
+#pragma unroll
+    for (int pg = 0; pg < NPG; ++pg) pos_lo[pg] = pos_hi[pg] = 0u;
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
       const int S = S0 + s;
@@ -263,101 +343,148 @@ __global__ __launch_bounds__(256, 2) void x6_program_kernel(const XpArgs a) {
       // NP pieces of slab S + 1 may stay in flight (vector-memory operations retire in order; loads and stores of this wave
       // issued since are older than them or make the wait stricter, never laxer)
       if (S + 1 < n_slabs) {
-        if constexpr (G::NP == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (G::NP == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (G::NP == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
-      if (S + 2 < n_slabs) dma_slab(S + 2, smem + ((slot + 2) % G::Slots) * G::SlabB);
+      // slab S + 2 goes into the slot slab S - 1 has left.  Its pieces are issued one per k-step, each at a point where none of
+      // this wave's LDS reads is outstanding.  (Measured, round 3: a vector-memory instruction -- slab piece or store -- issued
+      // between the matrix instructions while fragment reads were in flight gave sporadic wrong results in single waves at full
+      // grid sizes, counted or full waits alike; issued at these points never.  DESIGN.md 3.8.)
+      const bool more = S + 2 < n_slabs;
+      char* const nslot = smem + ((slot + 2) % G::Slots) * G::SlabB;
       const unsigned sl = lds0 + slot * G::SlabB + lane_row;
-      f32x4 acc, sm = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[NPG], sm[NPG];
       xp_u32x4 fr[2][3];
-      if constexpr (KF == 256) {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:8192\n\tds_read_b128 %3, %5 offset:16384"
-                     : "=&v"(acc), "=&v"(fr[0][0]), "=&v"(fr[0][1]), "=&v"(fr[0][2])
-                     : "v"(bias_l + 64 * s), "v"(sl + (((0 + g) ^ p) << 4)));
-      } else {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:4096\n\tds_read_b128 %3, %5 offset:8192"
-                     : "=&v"(acc), "=&v"(fr[0][0]), "=&v"(fr[0][1]), "=&v"(fr[0][2])
-                     : "v"(bias_l + 64 * s), "v"(sl + (((0 + g) ^ p) << 4)));
-      }
+#ifdef XP_NO_FRAG
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "=v"(fr[0][0]), "=v"(fr[0][1]), "=v"(fr[0][2]), "=v"(fr[1][0]), "=v"(fr[1][1]), "=v"(fr[1][2]));
+#else
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:%6\n\tds_read_b128 %3, %5 offset:%7"
+                   : "=&v"(acc[0]), "=&v"(fr[0][0]), "=&v"(fr[0][1]), "=&v"(fr[0][2])
+                   : "v"(bias_l + 64 * s), "v"(sl + (((0 + g) ^ p) << 4)), "n"(G::TermB), "n"(2 * G::TermB));
+#endif
 #pragma unroll
       for (int st = 0; st < KS; ++st) {
         const int c = st & 1, n = c ^ 1;
-        if (st + 1 < KS) {
-          if constexpr (KF == 256) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:8192\n\tds_read_b128 %2, %7 offset:16384"
-                         : "=&v"(fr[n][0]), "=&v"(fr[n][1]), "=&v"(fr[n][2]), "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc)
-                         : "v"(sl + (((4 * (st + 1) + g) ^ p) << 4)));
-          } else {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:4096\n\tds_read_b128 %2, %7 offset:8192"
-                         : "=&v"(fr[n][0]), "=&v"(fr[n][1]), "=&v"(fr[n][2]), "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc)
-                         : "v"(sl + (((4 * (st + 1) + g) ^ p) << 4)));
-          }
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc));
+        if (st < G::NP && more) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma_piece(s + 2 < NB ? img0 : img1, ((s + 2) % NB) * 16, nslot, st);
         }
-#define XPMM(A, B, C) \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xp_bf16x8, fr[c][A]), __builtin_bit_cast(xp_bf16x8, tb[B][st]), C, 0, 0, 0)
-        XPMM(2, 0, sm);
-        XPMM(0, 0, acc);
-        XPMM(0, 2, sm);
-        XPMM(1, 0, acc);
-        XPMM(1, 1, sm);
-        XPMM(0, 1, acc);
+#ifdef XP_NO_FRAG
+        if (false) {
+#else
+        if (st + 1 < KS) {
+#endif
+          asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:%8\n\tds_read_b128 %2, %7 offset:%9"
+                       : "=&v"(fr[n][0]), "=&v"(fr[n][1]), "=&v"(fr[n][2]), "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc[0])
+                       : "v"(sl + (((4 * (st + 1) + g) ^ p) << 4)), "n"(G::TermB), "n"(2 * G::TermB));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc[0]));
+        }
+        if (st == 0) {
+#pragma unroll
+          for (int pg = 0; pg < NPG; ++pg) {
+            if (pg > 0) acc[pg] = acc[0];  // (the bias row is the same for every point group)
+            sm[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#ifdef XP_NO_MFMA
+#define XPMM(A, B, C, PG) asm volatile("" : "+v"(C[PG]) : "v"(fr[c][A]), "v"(tb[PG][B][st]))
+#else
+#define XPMM(A, B, C, PG)                                                                                            \
+  C[PG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xp_bf16x8, fr[c][A]),                           \
+                                                  __builtin_bit_cast(xp_bf16x8, tb[PG][B][st]), C[PG], 0, 0, 0)
+#endif
+        // six products per point group; consecutive instructions never share an accumulator
+        if constexpr (NPG == 1) {
+          XPMM(2, 0, sm, 0);
+          XPMM(0, 0, acc, 0);
+          XPMM(0, 2, sm, 0);
+          XPMM(1, 0, acc, 0);
+          XPMM(1, 1, sm, 0);
+          XPMM(0, 1, acc, 0);
+        } else {
+          XPMM(2, 0, sm, 0);
+          XPMM(2, 0, sm, 1);
+          XPMM(0, 0, acc, 0);
+          XPMM(0, 0, acc, 1);
+          XPMM(0, 2, sm, 0);
+          XPMM(0, 2, sm, 1);
+          XPMM(1, 0, acc, 0);
+          XPMM(1, 0, acc, 1);
+          XPMM(1, 1, sm, 0);
+          XPMM(1, 1, sm, 1);
+          XPMM(0, 1, acc, 0);
+          XPMM(0, 1, acc, 1);
+        }
 #undef XPMM
       }
-      acc += sm;
-      if (has_add) acc += cur[s];
-      if (relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+      for (int pg = 0; pg < NPG; ++pg) {
+        f32x4 r = acc[pg] + sm[pg];
+        if (has_add) r += cur[pg][s];
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+        }
+        cur[pg][s] = r;  // (block s of the input is dead: its terms are in tb)
+        if (out != nullptr) __builtin_nontemporal_store(r, pt32(out, pg, s));
+        if constexpr (NB <= 16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) (s < 8 ? pos_lo[pg] : pos_hi[pg]) |= (unsigned)(r[e] > 0.f) << (4 * (s & 7) + e);
+        }
       }
-      cur[s] = acc;  // (block s of the input is dead: its terms are in tb)
-      if (out != nullptr) __builtin_nontemporal_store(acc, (f32x4*)(out + s * 512));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pos_bits |= (unsigned long long)(acc[e] > 0.f) << (4 * s + e);
       slot = (slot + 1) % G::Slots;
     }
     S0 += NB;
     ++jm;
     // ---------------------------------------------------------------- output side behind the last slab
-    if (post) {
+    if constexpr (NB <= 16) if (post) {
       // softmax over the first softmax_n features (keys) of scale * cur, fp32 with max subtraction (attention.py:158-164;
       // the scale is DotAttender's 1 / sqrt(kq_size), :217-218).  Feature 16 b + 4 g + e: a lane holds NB * 4 keys.
       const float sc = o.softmax_scale;
       const int n_valid = o.softmax_n;
-      float mx = -INFINITY;
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int pg = 0; pg < NPG; ++pg) {
+        float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool ok = 16 * b + 4 * g + e < n_valid;
-          cur[b][e] = ok ? sc * cur[b][e] : -INFINITY;
-          mx = fmaxf(mx, cur[b][e]);
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = 16 * b + 4 * g + e < n_valid;
+            cur[pg][b][e] = ok ? sc * cur[pg][b][e] : -INFINITY;
+            mx = fmaxf(mx, cur[pg][b][e]);
+          }
+        mx = xp_max4(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cur[pg][b][e] = expf(cur[pg][b][e] - mx);  // (exp(-inf) = 0 for the padding keys)
+            sum += cur[pg][b][e];
+          }
+        sum = xp_sum4(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cur[pg][b][e] *= inv;
+        if (o.store_out != nullptr && valid) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) __builtin_nontemporal_store(cur[pg][b], pt32(o.store_out, pg, b));
         }
-      mx = xp_max4(mx);
-      float sum = 0.f;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cur[b][e] = expf(cur[b][e] - mx);  // (exp(-inf) = 0 for the padding keys)
-          sum += cur[b][e];
-        }
-      sum = xp_sum4(sum);
-      const float inv = 1.f / sum;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cur[b][e] *= inv;
-      if (o.store_out != nullptr && valid) {
-        float* d = o.store_out + lane_off;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) __builtin_nontemporal_store(cur[b], (f32x4*)(d + b * 512));
       }
     }
-    if (o.store_bits != nullptr && valid) o.store_bits[bits_off] = pos_bits;
+    if constexpr (NB <= 16) {
+      if (o.store_bits != nullptr && valid) {
+#pragma unroll
+        for (int pg = 0; pg < NPG; ++pg) o.store_bits[bits_off + 64 * pg + lane] = ((unsigned long long)pos_hi[pg] << 32) | pos_lo[pg];
+      }
+    }
   }
 
   if (a.out_rows != nullptr) {
@@ -365,23 +492,26 @@ __global__ __launch_bounds__(256, 2) void x6_program_kernel(const XpArgs a) {
     // point's features, four fp32 dot products over them, summed over the point's four lanes.  W_out goes where the ring was.
     __syncthreads();  // (every wave is done with the last slabs)
     f32x4* wl = (f32x4*)smem;
-    if (tid < KF) wl[tid] = ((const f32x4*)a.out_w)[tid];
+    for (int i = tid; i < KF; i += 256) wl[i] = ((const f32x4*)a.out_w)[i];
     __syncthreads();
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int pg = 0; pg < NPG; ++pg) {
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const f32x4 w = wl[n * (KF / 4) + 4 * b + g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[n] = fmaf(w[e], cur[pg][b][e], r[n]);
+        }
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const f32x4 w = wl[n * (KF / 4) + 4 * b + g];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[n] = fmaf(w[e], cur[b][e], r[n]);
+        r[n] = xp_sum4(r[n]);
+        if (a.out_b != nullptr) r[n] += a.out_b[n];
       }
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      r[n] = xp_sum4(r[n]);
-      if (a.out_b != nullptr) r[n] += a.out_b[n];
+      if (valid && g == 0) ((f32x4*)a.out_rows)[row_off + 16 * pg + p] = r;
     }
-    if (valid && g == 0) ((f32x4*)a.out_rows)[row_idx] = r;
   }
 }
 
@@ -457,10 +587,13 @@ __global__ __launch_bounds__(256) void x6_task_images_kernel(const float* __rest
 
 }  // namespace npf
 
-extern "C" int npf_x6_run(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
-                          int32_t n_tasks, int32_t tiles_per_task, int32_t per_task, int32_t width, void* stream) {
+extern "C" int npf_x6_run_ex(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
+                             int32_t n_tasks, int32_t tiles_per_task, int32_t pts_per_task, int32_t per_task, int32_t width,
+                             int32_t variant, void* stream) {
   if (!ops || n_ops <= 0 || n_ops > NPF_X6_MAX_OPS || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
-  if (width != 128 && width != 256) return NPF_EINVAL;
+  if (width != 128 && width != 256 && width != 512) return NPF_EINVAL;
+  if (pts_per_task <= 0 || pts_per_task > tiles_per_task * 32 || pts_per_task <= (tiles_per_task - 1) * 32) return NPF_EINVAL;
+  if (variant < 0 || variant > 2 || (variant == 2 && width != 256)) return NPF_EINVAL;
   if ((out_rows != nullptr) != (out_w != nullptr) || (out_b != nullptr && out_rows == nullptr)) return NPF_EINVAL;
   if ((((uintptr_t)out_w) | ((uintptr_t)out_rows)) & 15) return NPF_EINVAL;
   if (((uintptr_t)out_b) & 3) return NPF_EINVAL;
@@ -474,11 +607,15 @@ extern "C" int npf_x6_run(const npf_x6_op_t* ops, int32_t n_ops, const float* ou
     if (o.in_rows != nullptr && (o.in_n <= 0 || o.in_n > width || (o.in_n & 15))) return NPF_EINVAL;
     if (o.in_pt != nullptr || o.in_rows != nullptr) have_cur = true;
     if (!have_cur) return NPF_EINVAL;  // (the first op must bring an input)
+    if (o.reserved[0] & ~(NPF_X6_IN_RM | NPF_X6_ADD_RM)) return NPF_EINVAL;
+    if (((o.reserved[0] & NPF_X6_IN_RM) && !o.in_pt) || ((o.reserved[0] & NPF_X6_ADD_RM) && !o.addend)) return NPF_EINVAL;
     if ((((uintptr_t)o.in_pt) | ((uintptr_t)o.in_rows) | ((uintptr_t)o.in_w) | ((uintptr_t)o.in_b) | ((uintptr_t)o.pre_add) |
          ((uintptr_t)o.mask) | ((uintptr_t)o.sbwd_p) | ((uintptr_t)o.store_in) | ((uintptr_t)o.w_img) | ((uintptr_t)o.addend) |
          ((uintptr_t)o.store_out)) & 15)
       return NPF_EINVAL;
     if ((((uintptr_t)o.mask_bits) | ((uintptr_t)o.store_in_bits) | ((uintptr_t)o.store_bits)) & 7) return NPF_EINVAL;
+    // (a lane's ReLU bits are one 64-bit word: 16 blocks of 4 features; 512-wide programs are inference programs)
+    if (width > 256 && (o.mask_bits || o.store_in_bits || o.store_bits || o.sbwd_p || o.softmax_n)) return NPF_EINVAL;
     if (((uintptr_t)o.bias) & 3) return NPF_EINVAL;
     if ((o.w_task_stride & 15) || o.w_task_stride < 0 || o.bias_task_stride < 0) return NPF_EINVAL;
     if ((o.w_task_stride != 0 || o.bias_task_stride != 0) && !per_task) return NPF_EINVAL;
@@ -502,14 +639,28 @@ extern "C" int npf_x6_run(const npf_x6_op_t* ops, int32_t n_ops, const float* ou
   a.n_ops = n_ops;
   a.total_tiles = n_tasks * tiles_per_task;
   a.tiles_per_task = tiles_per_task;
-  a.wgs_per_task = per_task ? (tiles_per_task + 1) / 2 : 0;
-  const int n_wg = per_task ? n_tasks * a.wgs_per_task : (a.total_tiles + 1) / 2;
+  a.pts_per_task = pts_per_task;
+  // 256 features: a wave owns half a tile (two workgroups per CU) or a whole one (one wave per SIMD); the library's choice is in
+  // NPF_X6_DEFAULT_VARIANT (measured on the config-2 train step)
+  const int npg = width == 256 ? (variant == 0 ? NPF_X6_DEFAULT_VARIANT : variant) : 1;
+  const int tpw = npg == 2 ? 4 : 2;
+  a.wgs_per_task = per_task ? (tiles_per_task + tpw - 1) / tpw : 0;
+  const int n_wg = per_task ? n_tasks * a.wgs_per_task : (a.total_tiles + tpw - 1) / tpw;
   // the workgroups of a task share its keys / values: on one XCD (one L2) when the grid allows the renumbering
   a.xcd_remap = (per_task && (n_wg % 8) == 0 && a.wgs_per_task > 1) ? 1 : 0;
-  if (width == 256) hipLaunchKernelGGL(npf::x6_program_kernel<256>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(npf::x6_program_kernel<128>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(n_wg), block(256);
+  if (width == 512) hipLaunchKernelGGL((npf::x6_program_kernel<512, 1>), grid, block, 0, (hipStream_t)stream, a);
+  else if (width == 128) hipLaunchKernelGGL((npf::x6_program_kernel<128, 1>), grid, block, 0, (hipStream_t)stream, a);
+  else if (npg == 2) hipLaunchKernelGGL((npf::x6_program_kernel<256, 2>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((npf::x6_program_kernel<256, 1>), grid, block, 0, (hipStream_t)stream, a);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
+}
+
+extern "C" int npf_x6_run(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
+                          int32_t n_tasks, int32_t tiles_per_task, int32_t per_task, int32_t width, void* stream) {
+  return npf_x6_run_ex(ops, n_ops, out_w, out_b, out_rows, n_tasks, tiles_per_task, tiles_per_task * 32, per_task, width, 0,
+                       stream);
 }
 
 extern "C" int npf_x6_task_images(const float* src, int32_t n_tasks, int32_t pts, int32_t width, void* row_img, void* tr_img,

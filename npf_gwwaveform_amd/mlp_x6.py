@@ -23,12 +23,12 @@ ENABLED = os.environ.get("NPF_NO_MLP_X6", "0") != "1"
 WIDTH = 256
 
 
-def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List[List[torch.Tensor]]:
-    """Per weight matrix [256, 256] and per kind (1: of W, 2: of W^T) its three-term image [3, 256, 256] bf16 (k-permuted like
+def _three_term_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int], width: int = 256) -> List[List[torch.Tensor]]:
+    """Per weight matrix [F, F] (F = ``width``) and per kind (1: of W, 2: of W^T) its three-term image [3, F, F] bf16 (k-permuted like
     ``npf_cast_bf16_weights``): W0 = bf16(W), W1 = bf16(W - W0), W2 = bf16(W - W0 - W1), split and permuted by
     ``npf_prepare_weights`` (kinds 1 / 2 + 16 (s + 1)), one launch per 32 images, written in place."""
     n, dev = len(Ws), Ws[0].device
-    buf = torch.empty((len(kinds), n, 3, WIDTH, WIDTH), dtype=torch.bfloat16, device=dev)  # (the images land in place)
+    buf = torch.empty((len(kinds), n, 3, width, width), dtype=torch.bfloat16, device=dev)  # (the images land in place)
     specs = [(Ws[i].detach(), kind | ((s + 1) << 4)) for kind in kinds for i in range(n) for s in range(3)]
     CH.prepare_weights(specs, dsts=[buf[k, i, s] for k in range(len(kinds)) for i in range(n) for s in range(3)])
     return [[buf[k, i] for i in range(n)] for k in range(len(kinds))]

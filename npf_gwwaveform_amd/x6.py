@@ -23,13 +23,17 @@ from . import functional as FN
 # NPF_NO_X6_FUSED=1: the fused sides are off (the chain / mlp_x6 launches of round 2 run instead)
 ENABLED = os.environ.get("NPF_NO_X6_FUSED", "0") != "1"
 WIDTH = 256
+# points per wave of the 256-wide programs: 0 = the library's choice (NPF_X6_DEFAULT_VARIANT), 1 = 16 (two workgroups per CU),
+# 2 = 32 (one wave per SIMD); NPF_X6_VARIANT is a development / A-B switch
+VARIANT = int(os.environ.get("NPF_X6_VARIANT", "0"))
 
 
 class Program:
     """A list of ``npf_x6_op_t`` + geometry; ``launch()`` calls ``npf_x6_run``."""
 
-    def __init__(self, n_tasks: int, tiles: int, per_task: bool, width: int = WIDTH):
+    def __init__(self, n_tasks: int, tiles: int, per_task: bool, width: int = WIDTH, pts: Optional[int] = None):
         self.n_tasks, self.tiles, self.per_task, self.width = n_tasks, tiles, per_task, width
+        self.pts = tiles * 32 if pts is None else pts  # valid points per task (row-major operands are indexed with it)
         self.ops: List[dict] = []
         self.tail = None  # (W [4, F], b [4] or None, rows [points, 4])
         self.tag = ""     # which side / direction this launch is (bench.py lists the launches of a step by it)
@@ -59,10 +63,18 @@ class Program:
         flops = 0
         nbytes = 0
         for j, o in enumerate(self.ops):
+            flags = 0
             for k in ("in_pt", "pre_add", "mask", "sbwd_p", "store_in", "addend", "store_out"):
-                self._pt_ok(o.get(k), k)
-                setattr(arr[j], k, self._ptr(o.get(k), k))
-                nbytes += pts * F * 4 if o.get(k) is not None else 0
+                t = o.get(k)
+                if t is not None and o.get(k + "_rm"):  # a row-major [n_tasks, pts, F] operand (in_pt / addend only)
+                    if k not in ("in_pt", "addend") or tuple(t.shape) != (self.n_tasks, self.pts, F) or t.dtype != torch.float32:
+                        raise ValueError(f"x6 program operand {k}: row-major tensor {tuple(t.shape)} {t.dtype}")
+                    flags |= L.X6_IN_RM if k == "in_pt" else L.X6_ADD_RM
+                else:
+                    self._pt_ok(t, k)
+                setattr(arr[j], k, self._ptr(t, k))
+                nbytes += pts * F * 4 if t is not None else 0
+            arr[j].reserved[0] = flags
             for k in ("mask_bits", "store_in_bits", "store_bits"):
                 t = o.get(k)
                 if t is not None and (tuple(t.shape) != (self.n_tasks, self.tiles, 2, 64) or t.dtype != torch.int64):
@@ -110,10 +122,10 @@ class Program:
         if CH.PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        L.check(L.load().npf_x6_run(arr, len(self.ops), L.ptr(tail[0]) if tail else None,
-                                    L.ptr(tail[1]) if (tail and tail[1] is not None) else None,
-                                    L.ptr(tail[2]) if tail else None, self.n_tasks, self.tiles, int(self.per_task), F,
-                                    L.stream_ptr()), "npf_x6_run")
+        L.check(L.load().npf_x6_run_ex(arr, len(self.ops), L.ptr(tail[0]) if tail else None,
+                                       L.ptr(tail[1]) if (tail and tail[1] is not None) else None,
+                                       L.ptr(tail[2]) if tail else None, self.n_tasks, self.tiles, self.pts, int(self.per_task), F,
+                                       VARIANT if F == 256 else 0, L.stream_ptr()), "npf_x6_run_ex")
         if CH.PROFILE is not None:
             ev1.record()
             CH.PROFILE.append(("x6_program_kernel", flops, ev0, ev1, nbytes, self.tag))
@@ -140,10 +152,10 @@ def task_images(pt: torch.Tensor, pts: int, row: bool = True, tr: bool = True, w
     return ri, ti
 
 
-def _weight_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int]) -> List[List[torch.Tensor]]:
+def _weight_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int], width: int = WIDTH) -> List[List[torch.Tensor]]:
     from .mlp_x6 import _three_term_images
 
-    return _three_term_images(Ws, kinds)
+    return _three_term_images(Ws, kinds, width)
 
 
 def _bits(n_tasks, tiles, dev):
@@ -164,6 +176,50 @@ def _first_layer_matrix(W: torch.Tensor, n_out: int) -> torch.Tensor:
     out = torch.zeros((4, n_out), dtype=torch.float32, device=W.device)
     out[:d, :n] = W.detach().t()
     return out
+
+
+def decode_rows_usable(mod, x1: torch.Tensor, x2: torch.Tensor) -> bool:
+    """Does ``decode_rows`` cover this sum-merge module and these row-major inference inputs: fp32 mode, x1 / x2 / every hidden
+    layer F wide with F in (128, 256, 512), an output layer of <= 4 features, no residual, one x1 row per x2 row."""
+    from .architectures import MLP
+
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32" and mod.is_sum_merge and isinstance(mod.flat_module, MLP)):
+        return False
+    F = x1.shape[-1]
+    fm, rs = mod.flat_module, mod.resizer
+    if F not in (128, 256, 512) or x2.shape[-1] != F or x1.shape[:-1] != x2.shape[:-1] or fm.is_res or rs.is_res:
+        return False
+    if not (_square(rs.layers(), F) and _square([fm.to_hidden, *fm.linears], F) and fm.out.in_features == F
+            and fm.out.out_features <= 4):
+        return False
+    return len(rs.layers()) + len(fm.linears) + 1 <= L.NPF_X6_MAX_OPS and x1.shape[-2] > 0
+
+
+def decode_rows(mod, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """``MergeFlatInputs.forward`` at inference (encoders.py:175-183: flat(relu(x1 + resizer(x2)))) as ONE x6 program straight
+    from the row-major module-boundary tensors x1, x2 [n, T, F] -- what the reference's ``decode(X_trgt_enc, R_trgt)``
+    (base.py:327-367) hands its decoder: no layout pass, no per-layer HBM traffic, the F -> 2 dy output layer on the registers
+    the last hidden layer leaves.  Returns [n, T, n_out]."""
+    n, T, F = x1.shape
+    fm, rs = mod.flat_module, mod.resizer
+    lins = [*rs.layers(), fm.to_hidden, *fm.linears]
+    imgs = _weight_images([l.weight for l in lins], (1,), F)[0]
+    tiles = CH.tiles_of(T)
+    prog = Program(n, tiles, per_task=False, width=F, pts=T)
+    n_res = len(rs.layers())
+    for i, lin in enumerate(lins):
+        o = dict(img=imgs[i], bias=lin.bias.detach() if lin.bias is not None else None, relu=True)
+        if i == 0:
+            o.update(in_pt=x2.detach().contiguous(), in_pt_rm=True)
+        if i == n_res - 1:
+            o.update(addend=x1.detach().contiguous(), addend_rm=True)
+        prog.op(**o)
+    rows = torch.empty((n, tiles * 32, 4), dtype=torch.float32, device=x1.device)
+    Wo, bo = _pad_out(fm.out.weight, fm.out.bias)
+    prog.tail = (Wo, bo, rows)
+    prog.tag = f"decode (merge + {F}-wide decoder + output layer) from row-major inputs"
+    prog.launch()
+    return rows[:, :T, :fm.out.out_features]
 
 
 def _pad_out(W: torch.Tensor, b: Optional[torch.Tensor]):

@@ -99,11 +99,15 @@ def _target_side_f64(model, X, K, V):
     return out, P
 
 
-@pytest.mark.parametrize("B,C,T,L,dx,dy", [(2, 256, 64, 4, 1, 2), (3, 200, 96, 2, 2, 1), (1, 129, 32, 1, 1, 2), (2, 250, 70, 2, 1, 2)])
-def test_fused_target_side_matches_float64(B, C, T, L, dx, dy):
+@pytest.mark.parametrize("variant", [1, 2], ids=["16_points_per_wave", "32_points_per_wave"])
+@pytest.mark.parametrize("B,C,T,L,dx,dy", [(2, 256, 64, 4, 1, 2), (3, 200, 96, 2, 2, 1), (1, 129, 32, 1, 1, 2), (2, 250, 70, 2, 1, 2),
+                                           (3, 256, 288, 1, 1, 2)])
+def test_fused_target_side_matches_float64(B, C, T, L, dx, dy, variant, monkeypatch):
     from npf_gwwaveform_amd import chain as CH
     from npf_gwwaveform_amd import functional as FN
     from npf_gwwaveform_amd import x6
+
+    monkeypatch.setattr(x6, "VARIANT", variant)  # (both instances of the 256-wide program kernel, whatever the default is)
 
     model = _build(L=L, dx=dx, dy=dy, seed=B * 7 + C)
     assert x6.target_side_usable(model, C, T)
@@ -163,10 +167,13 @@ def _context_side_f64(model, X, Y):
     return Xc, R, P
 
 
-@pytest.mark.parametrize("B,C,L,dx,dy", [(2, 256, 4, 1, 2), (3, 64, 2, 2, 1), (1, 32, 1, 1, 3), (2, 45, 2, 1, 2)])
-def test_fused_context_side_matches_float64(B, C, L, dx, dy):
+@pytest.mark.parametrize("variant", [1, 2], ids=["16_points_per_wave", "32_points_per_wave"])
+@pytest.mark.parametrize("B,C,L,dx,dy", [(2, 256, 4, 1, 2), (3, 64, 2, 2, 1), (1, 32, 1, 1, 3), (2, 45, 2, 1, 2), (5, 96, 1, 1, 2)])
+def test_fused_context_side_matches_float64(B, C, L, dx, dy, variant, monkeypatch):
     from npf_gwwaveform_amd import functional as FN
     from npf_gwwaveform_amd import x6
+
+    monkeypatch.setattr(x6, "VARIANT", variant)
 
     model = _build(L=L, dx=dx, dy=dy, seed=B * 11 + C)
     assert x6.context_side_usable(model, C)
@@ -188,3 +195,39 @@ def test_fused_context_side_matches_float64(B, C, L, dx, dy):
             continue
         assert p.grad is not None, k
         assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("F,n,T,L,dy", [(512, 2, 70, 4, 2), (512, 1, 4096, 4, 2), (256, 3, 100, 2, 1), (128, 2, 45, 3, 2), (512, 3, 33, 1, 2)])
+def test_decode_rows_from_row_major_inputs_matches_float64(F, n, T, L, dy):
+    """``decode(X_trgt_enc, R_trgt)`` at inference (base.py:327-367 -> encoders.py:175-183 -> mlp.py:95-109) as one x6 program from
+    the ROW-MAJOR tensors the reference's signature takes, at the widths the program kernel has instances for -- 512 is
+    BASELINE config 5's decoder -- with ragged target counts: against float64 at the fp32 tolerance (1e-5 of max|ref|)."""
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd import x6
+
+    torch.manual_seed(F + T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dec = A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, hidden_size=F), is_sum_merge=True)(F, F, 2 * dy).to(DEV)
+    with torch.no_grad():
+        for k, p in dec.named_parameters():
+            if k.endswith(".bias"):
+                p.uniform_(-0.05, 0.05)
+    g = torch.Generator().manual_seed(T)
+    x1 = torch.randn(n, T, F, generator=g) * 0.5
+    x2 = torch.randn(n, T, F, generator=g) * 0.5
+    assert x6.decode_rows_usable(dec, x1.to(DEV), x2.to(DEV))
+    with torch.no_grad():
+        got = dec(x1.to(DEV), x2.to(DEV))
+    assert tuple(got.shape) == (n, T, 2 * dy)
+    P = {k: v.detach().double().cpu() for k, v in dec.named_parameters()}
+    lin = lambda x, pre: torch.nn.functional.linear(x, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+
+    def mlp(x, pre, n_lin):
+        h = torch.relu(lin(x, pre + ".to_hidden"))
+        for i in range(n_lin):
+            h = torch.relu(lin(h, f"{pre}.linears.{i}"))
+        return lin(h, pre + ".out")
+
+    ref = mlp(torch.relu(x1.double() + mlp(x2.double(), "resizer", len(dec.resizer.linears))), "flat_module", len(dec.flat_module.linears))
+    assert_close(got, ref, tol=1e-5, what=f"decode rows F={F}")
