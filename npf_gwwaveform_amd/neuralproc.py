@@ -314,7 +314,17 @@ class LatentNeuralProcessFamily(NeuralProcessFamily):
     def _latent_path_pt(self, R, C, Xt_pt, Y_trgt, B, T):
         q_zCc = self._latent_dist_from(self._lat_input(R, B))
         if self.is_q_zCct and Y_trgt is not None:
-            R_t = self._encode_globally_pt(Xt_pt, Y_trgt, B, T)
+            if Xt_pt is None:
+                # (forward left the target side to one x6 program, which encodes the targets itself: the target-side latent
+                # encode of base.py:501-506 is the context-side program over the target points, or the chain launches)
+                if self._fused_context_side(T):
+                    from . import x6
+
+                    R_t = self._pool_pt(x6.context_side(self, self._X_trgt_raw, Y_trgt)[1], B)
+                else:
+                    R_t = self._encode_globally_pt(self._xenc_pt(self._X_trgt_raw), Y_trgt, B, T)
+            else:
+                R_t = self._encode_globally_pt(Xt_pt, Y_trgt, B, T)
             q_zCct = self._latent_dist_from(self._lat_input(R_t, B))
             sampling_dist = q_zCct
         else:
@@ -559,15 +569,27 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
         R_det = AttnCNP.trgt_dependent_representation(self, X_cntxt, None, R, X_trgt).squeeze(0)
         return self.merge_r_z(R_det, z)
 
+    def _fused_target_side(self, C, T) -> bool:
+        """One latent sample, scaled-dot attention over <= 256 context points, 256-wide layers: the whole target side --
+        x-encoder, attention, merge_r_z, decoder -- is one x6 program (x6.target_side with the latent merge)."""
+        from . import x6
+
+        return (type(self) is AttnLNP and self.n_z_samples == 1 and self.z_dim == self.r_dim
+                and x6.target_side_usable(self, C, T, latent_merge=True))
+
     def _target_suffstat(self, Xc_pt, z_samples, R, Xt_pt, B, C, T):
         n_z = z_samples.size(0)
-        dev = Xt_pt.t.device
+        dev = z_samples.device
         W, b, r = self.r_z_merger.weight, self.r_z_merger.bias, self.r_dim
         # the latent half of merge_r_z is constant per (z-sample, task): a per-task bias
         rows = n_z * B
         chz = Chain(1, rows, dev)
         chz.input_pt(FN.pack_pt(z_samples.reshape(1, rows, self.z_dim)), self.z_dim).linear(W[:, r:], b).output_pt()
         zb = FN.unpack_pt(chz.run()[0], rows, pad32(r)).reshape(rows, pad32(r))
+        if Xt_pt is None:  # (the fused target side: one launch forward, one for its dgrad)
+            from . import x6
+
+            return x6.target_side(self, self._X_trgt_raw, Xc_pt, R, zb=zb)
         if n_z == 1:
             ch = Chain(B, T, dev, wg_per_task=True)
             if C == 0:

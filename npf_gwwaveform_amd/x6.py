@@ -240,13 +240,15 @@ class _TargetSideFn(torch.autograd.Function):
     """rows [B, T, n_out] = decoder(x_encoder(X_trgt), attention(x_encoder(X_trgt), K, V)).
 
     Arguments: X [B, T, dx] raw target features; K_pt, V_pt PT32 [B, tilesC, 64, 32, 4] (encoded context points /
-    their representations), C context points; ``spec`` = (n_xenc, n_res, n_flat): numbers of 256 -> 256 layers of the x-encoder
-    behind its first layer, of the resizer, of the flat MLP in front of its output layer; params = W, b pairs in the order
-    x-encoder (first layer, then the 256 -> 256 ones), resizer, flat, output layer."""
+    their representations), C context points; ``spec`` = (n_xenc, n_mrz, n_res, n_flat): numbers of 256 -> 256 layers of the
+    x-encoder behind its first layer, of the latent merge (0 or 1: AttnLNP's merge_r_z, base.py:554-575 / attnnp.py:183-202, as
+    relu(W_R R_trgt + zb[task]) -- the z half of the concatenated input is constant per task and enters as the per-task bias
+    ``zb`` [B, 256]), of the resizer, of the flat MLP in front of its output layer; params = W, b pairs in the order x-encoder
+    (first layer, then the 256 -> 256 ones), merge (W_R, None), resizer, flat, output layer."""
 
     @staticmethod
-    def forward(ctx, X, K_pt, V_pt, C, scale, spec, *params):
-        n_x, n_res, n_flat = spec
+    def forward(ctx, X, K_pt, V_pt, C, scale, spec, zb, *params):
+        n_x, n_mrz, n_res, n_flat = spec
         B, T, dx = X.shape
         dev = X.device
         tiles = T // 32
@@ -254,7 +256,9 @@ class _TargetSideFn(torch.autograd.Function):
         W1, b1 = Ws[0], bs[0]
         W_out, b_out = Ws[-1], bs[-1]
         n_out = W_out.shape[0]
-        mid_W, mid_b = Ws[1:-1], bs[1:-1]  # the 256 -> 256 layers: x-encoder rest, resizer, flat
+        mid_W, mid_b = Ws[1:-1], bs[1:-1]  # the 256 -> 256 layers: x-encoder rest, latent merge, resizer, flat
+        if n_mrz:
+            mid_b[n_x] = zb
         train = any(ctx.needs_input_grad)
         imgs = _weight_images(mid_W, (1, 2) if train else (1,))
         fw = imgs[0]
@@ -288,11 +292,12 @@ class _TargetSideFn(torch.autograd.Function):
         prog.op(img=K_row, img_per_task=True, softmax_n=C, softmax_scale=scale, store_out=P, true_n=C)
         R_trgt = pt() if train else None
         prog.op(img=V_tr, img_per_task=True, store_out=R_trgt, true_k=C)
-        # decoder: resizer, merge relu(x1 + .) (encoders.py:178-179), flat MLP
-        for i in range(n_res + n_flat):
+        # [latent merge relu(W_R R_trgt + zb[task])], decoder: resizer, merge relu(x1 + .) (encoders.py:178-179), flat MLP
+        for i in range(n_mrz + n_res + n_flat):
             j = n_x + i
-            o = dict(img=fw[j], bias=mid_b[j].detach() if mid_b[j] is not None else None, relu=True)
-            if i == n_res - 1:
+            o = dict(img=fw[j], bias=mid_b[j].detach().contiguous() if mid_b[j] is not None else None, relu=True,
+                     bias_per_task=bool(n_mrz and i == 0))
+            if i == n_mrz + n_res - 1:
                 o["addend"] = Xt_enc
             if train:
                 o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
@@ -315,11 +320,12 @@ class _TargetSideFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        n_x, n_res, n_flat = ctx.spec
-        n_mid = n_x + n_res + n_flat
+        n_x, n_mrz, n_res, n_flat = ctx.spec
+        n_dec = n_mrz + n_res + n_flat
+        n_mid = n_x + n_dec
         n_par = 2 * (n_mid + 2)
         if g is None:
-            return (None,) * (6 + n_par)
+            return (None,) * (7 + n_par)
         B, T, tiles, dx, C, scale, n_out = ctx.geom
         sv = list(ctx.saved_tensors)
         X4, h1, bits_h1, Xt_enc, P, R_trgt = sv[:6]
@@ -335,18 +341,18 @@ class _TargetSideFn(torch.autograd.Function):
         d_acts, d_bits = acts[n_x - 1:], bits[n_x - 1:]
         prog = Program(B, tiles, per_task=True)
         dz = [None] * n_mid  # dZ of every 256 -> 256 layer (index as in the forward: x-encoder, resizer, flat)
-        # decoder layers, last to first
-        for i in range(n_res + n_flat - 1, -1, -1):
+        # decoder layers (and the latent merge), last to first
+        for i in range(n_dec - 1, -1, -1):
             j = n_x + i
             dz[j] = pt()
             o = dict(mask_bits=d_bits[i], store_in=dz[j], img=bw[j])
-            if i == n_res + n_flat - 1:
+            if i == n_dec - 1:
                 o.update(in_rows=g4, in_w=Wo)  # the dgrad of the output layer in the prologue
             prog.op(**o)
         # attention backward: dO -> dP = V dO ; dS = softmax'(dP) ; dq = K^T dS, + the merge's gradient wrt x1 (fan-in)
         dO, dS = pt(), pt()
         prog.op(store_in=dO, img=V_row, img_per_task=True, true_n=C)
-        prog.op(sbwd_p=P, sbwd_scale=scale, store_in=dS, img=K_tr, img_per_task=True, addend=dz[n_x + n_res - 1], true_k=C)
+        prog.op(sbwd_p=P, sbwd_scale=scale, store_in=dS, img=K_tr, img_per_task=True, addend=dz[n_x + n_mrz + n_res - 1], true_k=C)
         # x-encoder, last to first; the first layer's dZ behind its ReLU mask closes the program
         for i in range(n_x - 1, -1, -1):
             dz[i] = pt()
@@ -368,7 +374,7 @@ class _TargetSideFn(torch.autograd.Function):
         ins = [h1, *x_acts, R_trgt, *d_acts[:-1]]  # input of every 256 -> 256 layer
         for j in range(n_mid):
             dW = torch.empty((WIDTH, WIDTH), dtype=torch.float32, device=dev)
-            db = torch.empty((WIDTH,), dtype=torch.float32, device=dev) if ctx.has_b[1 + j] else None
+            db = torch.empty((WIDTH,), dtype=torch.float32, device=dev) if (ctx.has_b[1 + j] and not (n_mrz and j == n_x)) else None
             jobs.append(dict(dZ=dz[j], A=ins[j], N=WIDTH, K=WIDTH, dW=dW, db=db))
             grads += [dW, db]
         dz_out = torch.zeros(CH.pt_shape(B, T, 4), dtype=torch.float32, device=dev)
@@ -387,16 +393,19 @@ class _TargetSideFn(torch.autograd.Function):
             jobs.append(dict(dZ=dS, A=Xt_enc, N=C, K=WIDTH, dW=dK, per_task=True, ldz=WIDTH))
         CH.run_wgrad(jobs, B, T, dev, tag="target side weight / key / value gradients")
         grads[0] = dW1p[:, :dx].contiguous() if dx != 4 else dW1p
-        return (None, dK, dV, None, None, None, *grads)
+        # the per-task bias of the latent merge: the sum of its dZ over the task's points (padding points carry zeros: their
+        # incoming gradient is zero)
+        d_zb = FN.sum_points_pt(dz[n_x], T, WIDTH)[:, :WIDTH].contiguous() if (n_mrz and ctx.needs_input_grad[6]) else None
+        return (None, dK, dV, None, None, None, d_zb, *grads)
 
 
 def _square(lins, width=WIDTH) -> bool:
     return all(l.in_features == width and l.out_features == width for l in lins)
 
 
-def target_side_usable(model, C: int, T: int) -> bool:
-    """Does the fused target side cover this model and batch: AttnCNP-style deterministic path with scaled-dot attention over
-    128 < C <= 256 context points, every wide layer 256 -> 256, no residual / dropout, whole tiles of targets."""
+def target_side_usable(model, C: int, T: int, latent_merge: bool = False) -> bool:
+    """Does the fused target side cover this model and batch: scaled-dot attention over 128 < C <= 256 context points, every
+    wide layer 256 -> 256, no residual / dropout; ``latent_merge``: with AttnLNP's merge_r_z between attention and decoder."""
     from .architectures import MLP, DotAttender
 
     if not (ENABLED and CH.COMPUTE_DTYPE == "fp32"):
@@ -418,27 +427,36 @@ def target_side_usable(model, C: int, T: int) -> bool:
     if not (_square(rs.layers()) and _square([fm.to_hidden, *fm.linears]) and fm.out.in_features == WIDTH
             and fm.out.out_features <= 4):
         return False
+    n_mrz = int(latent_merge)
+    if n_mrz:
+        mz = getattr(model, "r_z_merger", None)
+        if mz is None or mz.out_features != WIDTH or mz.in_features <= WIDTH or model.r_dim != WIDTH:
+            return False
     n_x, n_res, n_flat = len(xe.linears) + 1, len(rs.layers()), len(fm.linears) + 1
-    # forward: n_x + 2 + n_res + n_flat ops; dgrad: the same + 1
-    return n_x + 2 + n_res + n_flat + 1 <= L.NPF_X6_MAX_OPS
+    # forward: n_x + 2 + n_mrz + n_res + n_flat ops; dgrad: the same + 1
+    return n_x + 2 + n_mrz + n_res + n_flat + 1 <= L.NPF_X6_MAX_OPS
 
 
-def target_side(model, X_trgt: torch.Tensor, K: CH.PTensor, V: CH.PTensor) -> torch.Tensor:
-    """The decoder's sufficient statistics [B, T, 2 dy] of an attentive deterministic model from the raw target features and
-    the context side's PT32 outputs (``target_side_usable`` must hold)."""
+def target_side(model, X_trgt: torch.Tensor, K: CH.PTensor, V: CH.PTensor, zb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The decoder's sufficient statistics [B, T, 2 dy] of an attentive model from the raw target features and the context
+    side's PT32 outputs (``target_side_usable`` must hold).  ``zb`` [B, 256]: the latent half of AttnLNP's merge_r_z,
+    W_z z + b per task (one latent sample) -- the merge then runs between attention and decoder as relu(W_R R_trgt + zb)."""
     xe, dec, att = model.x_encoder, model.decoder, model.attender
     fm, rs = dec.flat_module, dec.resizer
     lins = [xe.to_hidden, *xe.linears, xe.out, *rs.layers(), fm.to_hidden, *fm.linears, fm.out]
     params = []
     for lin in lins:
         params += [lin.weight, lin.bias]
-    spec = (len(xe.linears) + 1, len(rs.layers()), len(fm.linears) + 1)
+    n_x = len(xe.linears) + 1
+    if zb is not None:
+        params[2 * (n_x + 1):2 * (n_x + 1)] = [model.r_z_merger.weight[:, :WIDTH], None]
+    spec = (n_x, int(zb is not None), len(rs.layers()), len(fm.linears) + 1)
     scale = 1.0 / math.sqrt(att.kq_size) if att.is_scale else 1.0
     T = X_trgt.shape[1]
     Tp = CH.pad32(T)
     if Tp != T:  # whole tiles of targets: the padding points (x = 0) are computed and dropped, their gradients are zero
         X_trgt = torch.nn.functional.pad(X_trgt, (0, 0, 0, Tp - T))
-    rows = _TargetSideFn.apply(X_trgt, K.t, V.t, K.pts, scale, spec, *params)
+    rows = _TargetSideFn.apply(X_trgt, K.t, V.t, K.pts, scale, spec, zb, *params)
     return rows if Tp == T else rows[:, :T].contiguous()
 
 

@@ -57,6 +57,8 @@ class _X6Rows:
         if not rows:
             return
         big = max(_grid(r) for r in rows)
+        if big == min(_grid(r) for r in rows):
+            return  # one grid size: not a train step with its two sides (e.g. the decode-only config): no per-launch rows
         for r in sorted(rows, key=lambda r: int(r.get("Dispatch_Id", 0))):
             did = int(r.get("Dispatch_Id", 0))
             if did in self.ids:
