@@ -386,15 +386,18 @@ typedef struct npf_x6_op {
  * R_trgt) is handed (npf/neuralproc/base.py:327) -- read without a layout pass (inference inputs: no gradient flows into them) */
 #define NPF_X6_IN_RM 1
 #define NPF_X6_ADD_RM 2
-/* 256-feature programs, the library's choice of points per wave (npf_x6_run_ex variant 0): 1 = 16 points (two workgroups per CU),
- * 2 = 32 points (one wave per SIMD, every weight fragment feeds twice the matrix instructions) */
-#define NPF_X6_DEFAULT_VARIANT 1
+/* 256-feature programs, the library's choice of kernel instance (npf_x6_run_ex variant 0): 1 = 16 points per wave, four waves per
+ * workgroup, two workgroups per CU; 2 = 32 points per wave (one wave per SIMD, every weight fragment feeds twice the matrix
+ * instructions); 3 = 16 points per wave, EIGHT waves per workgroup sharing one slab ring (a CU streams every slab once) */
+#define NPF_X6_DEFAULT_VARIANT 3
 /* out_rows != NULL: a F -> 4 layer behind the program, out_rows[point][n] = sum_f out_w[n][f] cur[f] + out_b[n] (the decoder's
  * output layer, mlp.py:109).  per_task != 0: every workgroup stays inside one task (required by per-task weights / biases).
  * width: 128 or 256. */
 /* npf_x6_run_ex: the same with pts_per_task valid points per task (<= 32 tiles_per_task; row-major operands are indexed with it),
  * width 128, 256 or 512 (512: no ReLU-bit operands -- inference programs, e.g. the r = 512 decoder of base.py:327-367 from
- * row-major inputs), and variant = 0 (library's choice) | 1 | 2 (NPF_X6_DEFAULT_VARIANT above; 2 needs width 256). */
+ * row-major inputs), and variant = 0 (library's choice) | 1 | 2 | 3: width 256 see NPF_X6_DEFAULT_VARIANT above; width 512: 1 = a wave
+ * holds all 512 features of its 16 points (one wave per SIMD), 0 / 2 = the contraction split over pairs of waves through LDS
+ * (two waves per SIMD; programs of plain layers -- inputs, multiply, bias / addend / ReLU, stores -- only; others take 1). */
 int npf_x6_run_ex(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const float *out_b, float *out_rows,
                   int32_t n_tasks, int32_t tiles_per_task, int32_t pts_per_task, int32_t per_task, int32_t width,
                   int32_t variant, void *stream);

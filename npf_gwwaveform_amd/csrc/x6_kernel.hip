@@ -106,13 +106,20 @@ __device__ __forceinline__ float xp_max4(float v) {
 // <256, 2>: a wave owns a whole tile -- every weight fragment read from LDS and every slab piece streamed from L2 feeds twice the
 // matrix instructions -- and <512, 1>: 512 features of 16 points; both keep 320 registers of activation terms and run one wave
 // per SIMD (512 registers).
-template <int KF, int NPG>
-__global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_kernel(const XpArgs a) {
+// NW = waves per workgroup: 4, or 8 waves (<256, 1, 8>) that share ONE slab ring -- a CU then streams every slab once instead of
+// once per workgroup of 64 points (half the L2 -> LDS traffic and half the pieces per wave).
+// LA = slabs in flight ahead of the one being multiplied (ring of LA + 1 slots): 2, or 4 where one workgroup has the CU's LDS.
+template <int KF, int NPG, int NW, int LA = 2>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && KF * NPG <= 256) ? 2 : 1) void x6_program_kernel(const XpArgs a) {
   using G = XpGeom<KF>;
   constexpr int NB = G::NB, KS = G::KS;
-  constexpr int TPW = NPG == 2 ? 4 : 2;  // tiles per workgroup
+  constexpr int Slots = LA + 1;
+  static_assert(LA >= 2 && LA <= 4 && LA <= NB, "slab look-ahead");
+  constexpr int TPW = (NPG == 2 ? 4 : 2) * (NW / 4);  // tiles per workgroup
+  constexpr int NPW = 3 * G::PPT / NW;                  // slab pieces per wave
   static_assert(NPG == 1 || NPG == 2, "a wave owns half a tile or a whole one");
-  __shared__ __attribute__((aligned(16))) char smem[G::Slots * G::SlabB + G::BiasB];
+  static_assert((NW == 4 || NW == 8) && (3 * G::PPT) % NW == 0 && NPW <= KS, "pieces dealt evenly, one per k-step");
+  __shared__ __attribute__((aligned(16))) char smem[Slots * G::SlabB + G::BiasB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
@@ -162,11 +169,11 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
   // DMA of a slab: 3 * PPT pieces of 1 KiB (term q / PPT, rows RPP (q % PPT) ..), NP per wave; the swizzle (chunk c of row r at
   // position c ^ (r & 15)) is applied to the source address: uniform base per piece + a lane offset
   constexpr int LPR = 64 / G::RPP;  // lanes per row of a piece
-  constexpr int NDL = G::PPT / 4 > 0 ? G::PPT / 4 : 1;  // distinct first rows of a wave's pieces
+  constexpr int NDL = G::PPT / NW > 0 ? G::PPT / NW : 1;  // distinct first rows of a wave's pieces
   unsigned dma_lane[NDL];
 #pragma unroll
   for (int n = 0; n < NDL; ++n) {
-    const int r0 = G::RPP * ((wave + 4 * n) % G::PPT), row = r0 + lane / LPR, pos = lane % LPR;
+    const int r0 = G::RPP * ((wave + NW * n) % G::PPT), row = r0 + lane / LPR, pos = lane % LPR;
     dma_lane[n] = (unsigned)((lane / LPR) * G::RowB + ((pos ^ (row & 15)) << 4));
   }
   const int n_slabs = a.n_mm * NB;
@@ -178,21 +185,22 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
 #endif
     const char* base = img + (size_t)rows * G::RowB;
     asm volatile("" : "+s"(base));
-    const int q = wave + 4 * n, term = q / G::PPT, r0 = G::RPP * (q % G::PPT);
+    const int q = wave + NW * n, term = q / G::PPT, r0 = G::RPP * (q % G::PPT);
     xp_dma16(base + (size_t)term * ((size_t)KF * KF * 2) + r0 * G::RowB + dma_lane[n % NDL], slot + term * G::TermB + r0 * G::RowB);
   };
   auto mm_base = [&](int j) { return a.mm_img[j] + (size_t)task * a.mm_stride[j]; };
   auto dma_slab = [&](int S, char* slot) {
     const char* img = mm_base(S / NB);
 #pragma unroll
-    for (int n = 0; n < G::NP; ++n) dma_piece(img, (S % NB) * 16, slot, n);
+    for (int n = 0; n < NPW; ++n) dma_piece(img, (S % NB) * 16, slot, n);
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lane_row = (unsigned)(p * G::RowB);
-  float* bias_lds = (float*)(smem + G::Slots * G::SlabB);
+  float* bias_lds = (float*)(smem + Slots * G::SlabB);
 
-  if (n_slabs > 0) dma_slab(0, smem);
-  if (n_slabs > 1) dma_slab(1, smem + G::SlabB);
+#pragma unroll
+  for (int i = 0; i < LA; ++i)
+    if (n_slabs > i) dma_slab(i, smem + i * G::SlabB);
   int slot = 0, S0 = 0, jm = 0;  // ring slot of the next slab, its number, the multiply it belongs to
   f32x4 cur[NPG][NB];
 #pragma unroll
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
 
     // ---------------------------------------------------------------- the multiply
     // the bias into LDS (read back per slab; visible behind the barrier of the op's first slab)
-    for (int i = tid; i < KF; i += 256)
+    for (int i = tid; i < KF; i += NW * 64)
       bias_lds[(jm & 1) * KF + i] = o.bias != nullptr ? o.bias[(size_t)task * o.bias_task_stride + i] : 0.f;
     // the input as three packed bf16 terms (the B operands), once per op
     xp_u32x4 tb[NPG][3][KS];
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
     const char* const img1 = mm_base(jm + 1 < a.n_mm ? jm + 1 : jm);
     const bool post = NB <= 16 && o.softmax_n > 0;  // (the stores then follow the softmax; 512-wide programs have none)
     const float* const out = (o.store_out != nullptr && valid && !post) ? o.store_out : nullptr;  // (wave-uniform)
-    const unsigned bias_l = lds0 + G::Slots * G::SlabB + (jm & 1) * (KF * 4) + g * 16;
+    const unsigned bias_l = lds0 + Slots * G::SlabB + (jm & 1) * (KF * 4) + g * 16;
     const bool relu = o.relu != 0;
     unsigned pos_lo[NPG], pos_hi[NPG];  // the output's ReLU bits: blocks 0-7, 8-15
 #pragma unroll
@@ -342,19 +350,22 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
       // slab S has landed for everyone, everyone is done with slab S - 1 (whose slot slab S + 2 goes into).  Counted wait: the
       // NP pieces of slab S + 1 may stay in flight (vector-memory operations retire in order; loads and stores of this wave
       // issued since are older than them or make the wait stricter, never laxer)
-      if (S + 1 < n_slabs) {
-        if constexpr (G::NP == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if constexpr (G::NP == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      {
+        // (wave-uniform: how many later slabs have pieces in flight -- LA - 1, fewer at the end of the program)
+        const int rem = n_slabs - 1 - S;
+#define XP_WAIT(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory")
+        if (rem >= LA - 1) XP_WAIT((LA - 1) * NPW);
+        else if (LA > 3 && rem == 2) XP_WAIT(2 * NPW);
+        else if (LA > 2 && rem == 1) XP_WAIT(NPW);
+        else XP_WAIT(0);
+#undef XP_WAIT
       }
-      // slab S + 2 goes into the slot slab S - 1 has left.  Its pieces are issued one per k-step, each at a point where none of
+      // slab S + LA goes into the slot slab S - 1 has left.  Its pieces are issued one per k-step, each at a point where none of
       // this wave's LDS reads is outstanding.  (Measured, round 3: a vector-memory instruction -- slab piece or store -- issued
       // between the matrix instructions while fragment reads were in flight gave sporadic wrong results in single waves at full
       // grid sizes, counted or full waits alike; issued at these points never.  DESIGN.md 3.8.)
-      const bool more = S + 2 < n_slabs;
-      char* const nslot = smem + ((slot + 2) % G::Slots) * G::SlabB;
+      const bool more = S + LA < n_slabs;
+      char* const nslot = smem + ((slot + LA) % Slots) * G::SlabB;
       const unsigned sl = lds0 + slot * G::SlabB + lane_row;
       f32x4 acc[NPG], sm[NPG];
       xp_u32x4 fr[2][3];
@@ -369,9 +380,9 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
 #pragma unroll
       for (int st = 0; st < KS; ++st) {
         const int c = st & 1, n = c ^ 1;
-        if (st < G::NP && more) {
+        if (st < NPW && more) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          dma_piece(s + 2 < NB ? img0 : img1, ((s + 2) % NB) * 16, nslot, st);
+          dma_piece(s + LA < NB ? img0 : img1, ((s + LA) % NB) * 16, nslot, st);
         }
 #ifdef XP_NO_FRAG
         if (false) {
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
           for (int e = 0; e < 4; ++e) (s < 8 ? pos_lo[pg] : pos_hi[pg]) |= (unsigned)(r[e] > 0.f) << (4 * (s & 7) + e);
         }
       }
-      slot = (slot + 1) % G::Slots;
+      slot = (slot + 1) % Slots;
     }
     S0 += NB;
     ++jm;
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
     // point's features, four fp32 dot products over them, summed over the point's four lanes.  W_out goes where the ring was.
     __syncthreads();  // (every wave is done with the last slabs)
     f32x4* wl = (f32x4*)smem;
-    for (int i = tid; i < KF; i += 256) wl[i] = ((const f32x4*)a.out_w)[i];
+    for (int i = tid; i < KF; i += NW * 64) wl[i] = ((const f32x4*)a.out_w)[i];
     __syncthreads();
 #pragma unroll
     for (int pg = 0; pg < NPG; ++pg) {
@@ -511,6 +522,208 @@ __global__ __launch_bounds__(256, (KF * NPG <= 256) ? 2 : 1) void x6_program_ker
         if (a.out_b != nullptr) r[n] += a.out_b[n];
       }
       if (valid && g == 0) ((f32x4*)a.out_rows)[row_off + 16 * pg + p] = r;
+    }
+  }
+}
+
+// 512-feature programs with the contraction split over a PAIR of waves (npf_x6_run_ex, width 512, plain layers): wave (pg, kh)
+// holds features 256 kh .. 256 kh + 255 of point group pg -- 160 registers of activation and terms instead of 320, so two waves
+// per SIMD again -- multiplies its half of the inputs through the slab's 16 output rows and hands the partial sums of the rows
+// it does not own to its partner through LDS (1 KiB per slab and pair, read behind the next slab's barrier).  Eight waves = four
+// point groups x two halves share one slab ring: 6 pieces per wave and slab, as in the 256-wide instance.
+// Ops: in_pt / addend (PT32 or row-major), bias, relu, store_out, the F -> 4 layer behind the program.
+struct XwGeom {
+  static constexpr int KF = 512, NB = 32, NBH = 16, KS = 8;  // output slabs per multiply, blocks and k-steps per wave
+  static constexpr int RowB = KF * 2, TermB = 16 * RowB, SlabB = 3 * TermB, Slots = 3;
+  static constexpr int NP = 6;                                // 48 one-row pieces per slab, 8 waves
+  static constexpr int BiasB = 2 * KF * 4, XB = 2 * 4 * 1024;  // bias double buffer; exchange [slab parity][pair][64 lanes] float4
+};
+
+__global__ __launch_bounds__(512) void x6_wide512_kernel(const XpArgs a) {
+  using G = XwGeom;
+  constexpr int KF = G::KF, NB = G::NB, NBH = G::NBH, KS = G::KS;
+  __shared__ __attribute__((aligned(16))) char smem[G::Slots * G::SlabB + G::BiasB + G::XB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pg = wave >> 1, kh = wave & 1;
+  const int p = lane & 15, g = lane >> 4;
+  const long t_flat = (long)blockIdx.x * 2 + (pg >> 1);
+  const int half = pg & 1;
+  const bool valid = t_flat < a.total_tiles;
+  const long tile = valid ? t_flat : 0;
+  const int t_in = (int)(tile % a.tiles_per_task);
+  const size_t tk = (size_t)(tile / a.tiles_per_task);
+  const size_t tile_off = (size_t)tile * (KF * 32);
+  const unsigned lane_b = (unsigned)(((16 * half + p) * 4 + g * 128) * 4);
+  const size_t row_off = (size_t)tile * 32 + 16 * half;
+  auto pt32 = [&](const float* base, int b) -> f32x4* {  // block b of this wave's half (global block 16 kh + b)
+    return (f32x4*)((char*)const_cast<float*>(base + tile_off + (size_t)((16 * kh + b) * 512)) + lane_b);
+  };
+  auto rm32 = [&](const float* base, int b) -> const f32x4* {
+    int pt = t_in * 32 + 16 * half + p;
+    pt = pt < a.pts_per_task ? pt : a.pts_per_task - 1;
+    return (const f32x4*)(base + (tk * a.pts_per_task + (size_t)pt) * KF + 256 * kh + 4 * g + 16 * b);
+  };
+  // slab DMA: piece q = wave + 8 n (n < 6) = term q / 16, row q % 16 (one 1 KiB row per piece); chunk c of row r at c ^ (r & 15)
+  unsigned dma_lane[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) dma_lane[n] = (unsigned)((lane ^ ((wave + 8 * n) & 15)) << 4);
+  const int n_slabs = a.n_mm * NB;
+  auto dma_piece = [&](const char* img, int rows, char* slot, int n) {
+    const char* base = img + (size_t)rows * G::RowB;
+    asm volatile("" : "+s"(base));
+    const int q = wave + 8 * n, term = q >> 4, r0 = q & 15;
+    xp_dma16(base + (size_t)term * ((size_t)KF * KF * 2) + r0 * G::RowB + dma_lane[n & 1], slot + term * G::TermB + r0 * G::RowB);
+  };
+  auto dma_slab = [&](int S, char* slot) {
+    const char* img = a.mm_img[S / NB];
+#pragma unroll
+    for (int n = 0; n < G::NP; ++n) dma_piece(img, (S % NB) * 16, slot, n);
+  };
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lane_row = (unsigned)(p * G::RowB);
+  float* bias_lds = (float*)(smem + G::Slots * G::SlabB);
+  const unsigned xb0 = lds0 + G::Slots * G::SlabB + G::BiasB + (unsigned)(pg * 1024 + lane * 16);
+
+  if (n_slabs > 0) dma_slab(0, smem);
+  if (n_slabs > 1) dma_slab(1, smem + G::SlabB);
+  int slot = 0, S0 = 0, jm = 0;
+  f32x4 cur[NBH];
+#pragma unroll
+  for (int b = 0; b < NBH; ++b) cur[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int l = 0; l < a.n_ops; ++l) {
+    const npf_x6_op_t& o = a.op[l];
+    const int oflags = o.reserved[0];
+    if (o.in_pt != nullptr) {
+      if (oflags & NPF_X6_IN_RM) {
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) cur[b] = *rm32(o.in_pt, b);
+      } else {
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) cur[b] = *pt32(o.in_pt, b);
+      }
+    }
+    if (o.w_img == nullptr) continue;
+    for (int i = tid; i < KF; i += 512) bias_lds[(jm & 1) * KF + i] = o.bias != nullptr ? o.bias[i] : 0.f;
+    xp_u32x4 tb[3][KS];
+#pragma unroll
+    for (int st = 0; st < KS; ++st) xp_split(cur[2 * st], cur[2 * st + 1], tb[0][st], tb[1][st], tb[2][st]);
+    const bool has_add = o.addend != nullptr;
+    if (has_add) {
+      if (oflags & NPF_X6_ADD_RM) {
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) cur[b] = *rm32(o.addend, b);
+      } else {
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) cur[b] = *pt32(o.addend, b);
+      }
+    }
+    const char* const img0 = a.mm_img[jm];
+    const char* const img1 = a.mm_img[jm + 1 < a.n_mm ? jm + 1 : jm];
+    const float* const out = (o.store_out != nullptr && valid) ? o.store_out : nullptr;
+    const unsigned bias_l = lds0 + G::Slots * G::SlabB + (jm & 1) * (KF * 4) + g * 16;
+    const bool relu = o.relu != 0;
+    f32x4 hold = {0.f, 0.f, 0.f, 0.f};  // this wave's partial sums of the previous slab, when it owns that slab's rows
+    // the rows of slab s belong to the wave whose half of the features they are (kh == s / 16): behind the next barrier it adds its
+    // partner's partial sums and finishes the block
+    auto finish = [&](int s) {
+      if (kh == (s >> 4)) {
+        f32x4 x;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(xb0 + (s & 1) * 4096) : "memory");
+        f32x4 r = hold + x;
+        if (has_add) r += cur[s & 15];
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+        }
+        cur[s & 15] = r;
+        if (out != nullptr) __builtin_nontemporal_store(r, pt32(out, s & 15));
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const int S = S0 + s;
+      if (S + 1 < n_slabs) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (s > 0) finish(s - 1);
+      const bool more = S + 2 < n_slabs;
+      char* const nslot = smem + ((slot + 2) % G::Slots) * G::SlabB;
+      const unsigned sl = lds0 + slot * G::SlabB + lane_row;
+      const bool mine = kh == (s >> 4);
+      f32x4 acc, sm;
+      xp_u32x4 fr[2][3];
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:%6\n\tds_read_b128 %3, %5 offset:%7"
+                   : "=&v"(acc), "=&v"(fr[0][0]), "=&v"(fr[0][1]), "=&v"(fr[0][2])
+                   : "v"(bias_l + 64 * s), "v"(sl + (((4 * (8 * kh + 0) + g) ^ p) << 4)), "n"(G::TermB), "n"(2 * G::TermB));
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        const int c = st & 1, n = c ^ 1;
+        if (st < G::NP && more) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma_piece(s + 2 < NB ? img0 : img1, ((s + 2) % NB) * 16, nslot, st);
+        }
+        if (st + 1 < KS) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:%8\n\tds_read_b128 %2, %7 offset:%9"
+                       : "=&v"(fr[n][0]), "=&v"(fr[n][1]), "=&v"(fr[n][2]), "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc)
+                       : "v"(sl + (((4 * (8 * kh + st + 1) + g) ^ p) << 4)), "n"(G::TermB), "n"(2 * G::TermB));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[c][0]), "+v"(fr[c][1]), "+v"(fr[c][2]), "+v"(acc));
+        }
+        if (st == 0) {
+          if (!mine) acc = f32x4{0.f, 0.f, 0.f, 0.f};  // (the bias belongs to the owner's sum)
+          sm = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#define XWMM(A, B, C) \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xp_bf16x8, fr[c][A]), __builtin_bit_cast(xp_bf16x8, tb[B][st]), C, 0, 0, 0)
+        XWMM(2, 0, sm);
+        XWMM(0, 0, acc);
+        XWMM(0, 2, sm);
+        XWMM(1, 0, acc);
+        XWMM(1, 1, sm);
+        XWMM(0, 1, acc);
+#undef XWMM
+      }
+      const f32x4 part = acc + sm;
+      if (mine) {
+        hold = part;
+      } else {
+        asm volatile("ds_write_b128 %0, %1" : : "v"(xb0 + (s & 1) * 4096), "v"(part) : "memory");
+      }
+      slot = (slot + 1) % G::Slots;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    finish(NB - 1);
+    S0 += NB;
+    ++jm;
+  }
+
+  if (a.out_rows != nullptr) {
+    // the F -> 4 layer on the registers the program leaves: each wave of a pair over its 256 features, the partner's four partial
+    // dot products through the exchange buffer
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    f32x4* wl = (f32x4*)smem;
+    for (int i = tid; i < KF; i += 512) wl[i] = ((const f32x4*)a.out_w)[i];
+    __syncthreads();
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NBH; ++b)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 w = wl[n * (KF / 4) + 4 * (16 * kh + b) + g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[n] = fmaf(w[e], cur[b][e], r[n]);
+      }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) r[n] = xp_sum4(r[n]);
+    f32x4* xb = (f32x4*)(smem + G::Slots * G::SlabB + G::BiasB) + pg * 64 + lane;
+    if (kh == 1) *xb = r;
+    __syncthreads();
+    if (kh == 0) {
+      const f32x4 x = *xb;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) r[n] += x[n] + (a.out_b != nullptr ? a.out_b[n] : 0.f);
+      if (valid && g == 0) ((f32x4*)a.out_rows)[row_off + p] = r;
     }
   }
 }
@@ -593,7 +806,7 @@ extern "C" int npf_x6_run_ex(const npf_x6_op_t* ops, int32_t n_ops, const float*
   if (!ops || n_ops <= 0 || n_ops > NPF_X6_MAX_OPS || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
   if (width != 128 && width != 256 && width != 512) return NPF_EINVAL;
   if (pts_per_task <= 0 || pts_per_task > tiles_per_task * 32 || pts_per_task <= (tiles_per_task - 1) * 32) return NPF_EINVAL;
-  if (variant < 0 || variant > 2 || (variant == 2 && width != 256)) return NPF_EINVAL;
+  if (variant < 0 || variant > 3 || (variant >= 2 && width == 128) || (variant == 3 && width != 256)) return NPF_EINVAL;
   if ((out_rows != nullptr) != (out_w != nullptr) || (out_b != nullptr && out_rows == nullptr)) return NPF_EINVAL;
   if ((((uintptr_t)out_w) | ((uintptr_t)out_rows)) & 15) return NPF_EINVAL;
   if (((uintptr_t)out_b) & 3) return NPF_EINVAL;
@@ -640,19 +853,35 @@ extern "C" int npf_x6_run_ex(const npf_x6_op_t* ops, int32_t n_ops, const float*
   a.total_tiles = n_tasks * tiles_per_task;
   a.tiles_per_task = tiles_per_task;
   a.pts_per_task = pts_per_task;
-  // 256 features: a wave owns half a tile (two workgroups per CU) or a whole one (one wave per SIMD); the library's choice is in
-  // NPF_X6_DEFAULT_VARIANT (measured on the config-2 train step)
-  const int npg = width == 256 ? (variant == 0 ? NPF_X6_DEFAULT_VARIANT : variant) : 1;
-  const int tpw = npg == 2 ? 4 : 2;
+  // 256 features: 1 = a wave owns half a tile, four waves per workgroup, two workgroups per CU; 2 = a wave owns a whole tile (one
+  // wave per SIMD); 3 = as 1 with eight waves per workgroup sharing one slab ring.  The library's choice is
+  // NPF_X6_DEFAULT_VARIANT (measured on the config-2 train step: 3 -- 6.45 ms against 6.62 (1) and 7.85 (2))
+  const int var = width == 256 ? (variant == 0 ? NPF_X6_DEFAULT_VARIANT : variant) : 1;
+  const int npg = var == 2 ? 2 : 1;
+  const int tpw = var == 1 ? 2 : 4;
   a.wgs_per_task = per_task ? (tiles_per_task + tpw - 1) / tpw : 0;
   const int n_wg = per_task ? n_tasks * a.wgs_per_task : (a.total_tiles + tpw - 1) / tpw;
   // the workgroups of a task share its keys / values: on one XCD (one L2) when the grid allows the renumbering
   a.xcd_remap = (per_task && (n_wg % 8) == 0 && a.wgs_per_task > 1) ? 1 : 0;
   const dim3 grid(n_wg), block(256);
-  if (width == 512) hipLaunchKernelGGL((npf::x6_program_kernel<512, 1>), grid, block, 0, (hipStream_t)stream, a);
-  else if (width == 128) hipLaunchKernelGGL((npf::x6_program_kernel<128, 1>), grid, block, 0, (hipStream_t)stream, a);
-  else if (npg == 2) hipLaunchKernelGGL((npf::x6_program_kernel<256, 2>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((npf::x6_program_kernel<256, 1>), grid, block, 0, (hipStream_t)stream, a);
+  if (width == 512 && !per_task && variant != 1) {
+    // plain layers (inputs, multiply, bias / addend / ReLU, stores): the contraction split over pairs of waves, two waves per SIMD
+    bool plain = true;
+    for (int l = 0; l < n_ops; ++l) {
+      const npf_x6_op_t& o = ops[l];
+      if (o.in_rows || o.pre_add || o.mask || o.store_in) plain = false;
+    }
+    if (plain) {
+      hipLaunchKernelGGL(npf::x6_wide512_kernel, dim3((a.total_tiles + 1) / 2), dim3(512), 0, (hipStream_t)stream, a);
+      NPF_CHECK_LAUNCH();
+      return NPF_OK;
+    }
+  }
+  if (width == 512) hipLaunchKernelGGL((npf::x6_program_kernel<512, 1, 4>), grid, block, 0, (hipStream_t)stream, a);
+  else if (width == 128) hipLaunchKernelGGL((npf::x6_program_kernel<128, 1, 4>), grid, block, 0, (hipStream_t)stream, a);
+  else if (var == 2) hipLaunchKernelGGL((npf::x6_program_kernel<256, 2, 4>), grid, block, 0, (hipStream_t)stream, a);
+  else if (var == 3) hipLaunchKernelGGL((npf::x6_program_kernel<256, 1, 8, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((npf::x6_program_kernel<256, 1, 4>), grid, block, 0, (hipStream_t)stream, a);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

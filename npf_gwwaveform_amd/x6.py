@@ -23,8 +23,11 @@ from . import functional as FN
 # NPF_NO_X6_FUSED=1: the fused sides are off (the chain / mlp_x6 launches of round 2 run instead)
 ENABLED = os.environ.get("NPF_NO_X6_FUSED", "0") != "1"
 WIDTH = 256
-# points per wave of the 256-wide programs: 0 = the library's choice (NPF_X6_DEFAULT_VARIANT), 1 = 16 (two workgroups per CU),
-# 2 = 32 (one wave per SIMD); NPF_X6_VARIANT is a development / A-B switch
+# which instance of the program kernel runs (npf_x6_run_ex ``variant``): 0 = the library's choice; 256-wide programs: 1 = 16
+# points per wave, two workgroups of four waves per CU, 2 = 32 points per wave (one wave per SIMD), 3 = 16 points per wave, eight
+# waves sharing one slab ring (the default); 512-wide programs: 1 = one wave per 16 points
+# and all 512 features (one wave per SIMD), 0 / 2 = the contraction split over pairs of waves (plain layers only, two waves per
+# SIMD, the default).  NPF_X6_VARIANT is a development / A-B switch
 VARIANT = int(os.environ.get("NPF_X6_VARIANT", "0"))
 
 
@@ -125,7 +128,7 @@ class Program:
         L.check(L.load().npf_x6_run_ex(arr, len(self.ops), L.ptr(tail[0]) if tail else None,
                                        L.ptr(tail[1]) if (tail and tail[1] is not None) else None,
                                        L.ptr(tail[2]) if tail else None, self.n_tasks, self.tiles, self.pts, int(self.per_task), F,
-                                       VARIANT if F == 256 else 0, L.stream_ptr()), "npf_x6_run_ex")
+                                       VARIANT if F in (256, 512) else 0, L.stream_ptr()), "npf_x6_run_ex")
         if CH.PROFILE is not None:
             ev1.record()
             CH.PROFILE.append(("x6_program_kernel", flops, ev0, ev1, nbytes, self.tag))

@@ -99,7 +99,7 @@ def _target_side_f64(model, X, K, V):
     return out, P
 
 
-@pytest.mark.parametrize("variant", [1, 2], ids=["16_points_per_wave", "32_points_per_wave"])
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["16_points_per_wave", "32_points_per_wave", "8_waves_one_slab_ring"])
 @pytest.mark.parametrize("B,C,T,L,dx,dy", [(2, 256, 64, 4, 1, 2), (3, 200, 96, 2, 2, 1), (1, 129, 32, 1, 1, 2), (2, 250, 70, 2, 1, 2),
                                            (3, 256, 288, 1, 1, 2)])
 def test_fused_target_side_matches_float64(B, C, T, L, dx, dy, variant, monkeypatch):
@@ -167,7 +167,7 @@ def _context_side_f64(model, X, Y):
     return Xc, R, P
 
 
-@pytest.mark.parametrize("variant", [1, 2], ids=["16_points_per_wave", "32_points_per_wave"])
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["16_points_per_wave", "32_points_per_wave", "8_waves_one_slab_ring"])
 @pytest.mark.parametrize("B,C,L,dx,dy", [(2, 256, 4, 1, 2), (3, 64, 2, 2, 1), (1, 32, 1, 1, 3), (2, 45, 2, 1, 2), (5, 96, 1, 1, 2)])
 def test_fused_context_side_matches_float64(B, C, L, dx, dy, variant, monkeypatch):
     from npf_gwwaveform_amd import functional as FN
@@ -197,14 +197,18 @@ def test_fused_context_side_matches_float64(B, C, L, dx, dy, variant, monkeypatc
         assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
 
 
-@pytest.mark.parametrize("F,n,T,L,dy", [(512, 2, 70, 4, 2), (512, 1, 4096, 4, 2), (256, 3, 100, 2, 1), (128, 2, 45, 3, 2), (512, 3, 33, 1, 2)])
-def test_decode_rows_from_row_major_inputs_matches_float64(F, n, T, L, dy):
+@pytest.mark.parametrize("variant", [0, 1], ids=["default_instance", "variant_1"])
+@pytest.mark.parametrize("F,n,T,L,dy", [(512, 2, 70, 4, 2), (512, 1, 4096, 4, 2), (256, 3, 100, 2, 1), (128, 2, 45, 3, 2), (512, 3, 33, 1, 2),
+                                        (512, 5, 64, 2, 2)])
+def test_decode_rows_from_row_major_inputs_matches_float64(F, n, T, L, dy, variant, monkeypatch):
     """``decode(X_trgt_enc, R_trgt)`` at inference (base.py:327-367 -> encoders.py:175-183 -> mlp.py:95-109) as one x6 program from
     the ROW-MAJOR tensors the reference's signature takes, at the widths the program kernel has instances for -- 512 is
     BASELINE config 5's decoder -- with ragged target counts: against float64 at the fp32 tolerance (1e-5 of max|ref|)."""
     import npf_gwwaveform_amd as A
     from npf_gwwaveform_amd import x6
 
+    # (512 features: the default splits the contraction over pairs of waves, variant 1 keeps all 512 features in one wave)
+    monkeypatch.setattr(x6, "VARIANT", variant)
     torch.manual_seed(F + T)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
