@@ -13,6 +13,8 @@
 // registers, streams its tiles by LDS-DMA through a double-buffered, XOR-
 // swizzled LDS image (one barrier per tile) and writes one partial; a second tiny kernel sums
 // the partials of the workgroups that split the points (deterministic, no atomics).
+#include <cstdlib>
+
 #include "npf_common.hpp"
 
 namespace npf {
@@ -731,6 +733,224 @@ __global__ __launch_bounds__(kXThreads, 1) void wgrad_x6_kernel(const WgradJobs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction for 256 x 256 jobs with every operand value split ONCE per workgroup (round 3).  wgrad_x6_kernel is
+// vector-issue-bound: 4.1 vector instructions per MFMA (PMC), because each wave splits the fragments it reads itself -- the A-side
+// feature by the four row-block waves that use it, the dZ side by both column-pair waves: three times the unique work.  Here a
+// tile goes in HALVES of 16 points: the workgroup's 512 lanes load the half tile's 2 x 4096 fp32 values from HBM into registers
+// (four 16-byte loads per lane, issued a half tile ahead), each lane splits ITS 16 values (88 vector instructions) and writes the
+// three terms as bf16 rows [point][feature] into LDS (12 x ds_write_b64); the matrix phase reads its operands with the
+// hardware-transposing ds_read_b64_tr_b16 (4 points x 16 features per 16-lane group -> "lane = feature, elements = 4 points") and
+// runs v_mfma_f32_32x32x16_bf16 (K = the half tile's 16 points): wave (rg, cp) owns rows 64 rg.. (dZ features) x columns
+// 128 cp.. (A features) = 2 x 4 tiles of 32 x 32, 48 MFMAs of 32 cycles per half tile beside 88 + ~40 vector instructions.
+// Term images are double-buffered (2 x 54 KiB): the split of half tile h + 1 rides inside the matrix phase of h; one barrier
+// per half tile.  Measured (config 2, target-side launch: nine 256 x 256 jobs over 262 144 points + its narrow jobs and reduces):
+// 1.79 ms with wgrad_x6_kernel -> 1.50 ms; a first version without the software pipeline (split, then reads, then MFMAs) 1.92.
+// The transposed reads are the clang builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16: hipcc places the waits and builds the
+// 8-element operands without register copies; as inline asm the two halves of an operand cost four v_mov each).  NPF_NO_WGRAD_H16=1
+// keeps wgrad_x6_kernel.  LDS rows are 576 bytes apart: the transposed reads (rows q, q + 1 .. of two 16-feature blocks per 32-lane
+// half) and the row writes (lanes dealt as 4 points x 4 feature quads per 16 lanes) are both bank-conflict free.
+constexpr int kHRow = 576;                       // bytes between the rows (points) of a term image
+constexpr int kHTerm = 16 * kHRow;               // one term of one operand
+constexpr int kHBuf = 2 * 3 * kHTerm;            // (dZ, A) x three terms
+typedef unsigned h16_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned h16_u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512, 1) void wgrad_h16_kernel(const WgradJobs J, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kHBuf];
+  int j = 0;
+  while (j + 1 < J.n_jobs && (int)blockIdx.x >= J.first_wg[j + 1]) ++j;
+  const npf_wgrad_job_t& job = J.job[j];
+  const int split = blockIdx.x - J.first_wg[j];
+  const int n_split = J.first_wg[j + 1] - J.first_wg[j];
+  constexpr int Np = 256, Kp = 256;
+  const long total_tiles = (long)J.n_tasks * J.tiles_per_task;
+  long t0, t1;
+  int tstride = 1;
+  if (job.per_task) {
+    t0 = (long)split * J.tiles_per_task;
+    t1 = t0 + J.tiles_per_task;
+  } else {
+    t0 = split;
+    t1 = total_tiles;
+    tstride = n_split;
+  }
+  const long n_half = t1 > t0 ? 2 * ((t1 - t0 + tstride - 1) / tstride) : 0;  // half tiles of this workgroup
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave >> 1, cp = wave & 1;
+  // loads: lane = (p_lo, q, p_hi): point 4 p_hi + p_lo of the half tile, feature quad 8 wave + 4 jj + q (jj = 0, 1)
+  const int p_lo = lane & 3, q_ld = (lane >> 2) & 3, p_hi = lane >> 4;
+  const int pt_ld = 4 * p_hi + p_lo;
+  const int Zf = job.ldz > 0 ? job.ldz : Np, Af = job.lda > 0 ? job.lda : Kp;
+  const char* dz_base = (const char*)job.dZ;
+  const char* a_base = (const char*)job.A;
+  const unsigned ld_lane = (unsigned)(((8 * wave + q_ld) * 32 + pt_ld) * 16);  // byte offset inside the tile (jj = 0, half 0)
+  auto tile_of = [&](long h) { return t0 + (h >> 1) * tstride; };
+  // piece v of half tile h: v = 0, 1: dZ quads f4, f4 + 4; v = 2, 3: A
+  auto load_piece = [&](long h, int v) -> f32x4 {
+    const long t = tile_of(h);
+    const unsigned off = ld_lane + (unsigned)(h & 1) * 256u + (unsigned)(v & 1) * 2048u;
+    const char* src = (v < 2 ? dz_base + (size_t)t * Zf * 128 : a_base + (size_t)t * Af * 128) + off;
+    return *(const f32x4*)src;
+  };
+  // term rows in LDS: point pt at pt * kHRow, feature quad f4 at + 8 f4
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned st_lane = (unsigned)(pt_ld * kHRow + (8 * wave + q_ld) * 8);
+  // split one float4 (v = 0, 1: dZ quads f4, f4 + 4; v = 2, 3: A) into its three terms and write them as bf16 rows
+  auto split_store1 = [&](const f32x4& x, int v, unsigned buf) {
+    h16_u32x2 t[3];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const float a = x[2 * pr], b = x[2 * pr + 1];
+      const unsigned h = x6_cvt_pk(a, b);
+      const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+      const unsigned m = x6_cvt_pk(ra, rb);
+      const float la = ra - __builtin_bit_cast(float, m << 16), lb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+      t[0][pr] = h;
+      t[1][pr] = m;
+      t[2][pr] = x6_cvt_pk(la, lb);
+    }
+    const unsigned ad = lds0 + buf * kHBuf + (v >> 1) * 3 * kHTerm + st_lane + (v & 1) * 32;
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %0, %3 offset:%5"
+                 :
+                 : "v"(ad), "v"(t[0]), "v"(t[1]), "v"(t[2]), "n"(kHTerm), "n"(2 * kHTerm)
+                 : "memory");
+  };
+  // transposed operand reads: 16-lane group gq = lane >> 4: feature block (gq & 1), points 8 (gq >> 1) + 4 rd + q; lane 4 q + p
+  // of the group supplies row q, columns 4 p .. 4 p + 3
+  const int gq = lane >> 4, q_rd = (lane >> 2) & 3, p_rd = lane & 3;
+  const unsigned rd_lane = (unsigned)((8 * (gq >> 1) + q_rd) * kHRow + (16 * (gq & 1) + 4 * p_rd) * 2);
+  typedef short h16_s16x4 __attribute__((ext_vector_type(4)));
+  typedef short h16_s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) h16_s16x4 h16_lds_s16x4;
+  struct Frag { h16_s16x8 v; };
+  auto frag = [&](unsigned buf, int operand, int term, int feat0, Frag& f) {  // 32 features from feat0, the 16 points
+    const char* ad = lds + buf * kHBuf + (operand * 3 + term) * kHTerm + rd_lane + (unsigned)feat0 * 2;
+    const h16_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_lds_s16x4*)ad);
+    const h16_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_lds_s16x4*)(ad + 4 * kHRow));
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto op8 = [](const Frag& f) { return __builtin_bit_cast(bf16x8w, f.v); };
+
+  f32x16v acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+  f32x4 dbacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+  // One half tile: the matrix phase on buffer h & 1 with, riding between its MFMAs, the split of half tile h + 1 (in ``raw``,
+  // loaded a half tile ago) into the other buffer -- one float4 per column tile, its registers reloaded at once with the same
+  // piece of half tile h + 2 (a whole phase to land).  Past the end the pieces are stale: split and written all the same (the
+  // other buffer is not read any more; no branch inside the phase: the scheduler interleaves one basic block).
+  f32x4 raw[4];
+  auto body = [&](long h) {
+    const unsigned buf = (unsigned)(h & 1);
+    const float live = h + 1 < n_half ? 1.f : 0.f;
+    const long h2 = h + 2 < n_half ? h + 2 : (n_half > 0 ? n_half - 1 : 0);  // (clamped: a valid address either way)
+    Frag fa[2][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) frag(buf, 0, t, 64 * rg + 32 * i, fa[i][t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) frag(buf, 1, t, 128 * cp, fb[0][t]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cb = c & 1;
+      if (c + 1 < 4) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) frag(buf, 1, t, 128 * cp + 32 * (c + 1), fb[cb ^ 1][t]);
+      }
+#define HMM(I, TA, TB) \
+  acc[I][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op8(fa[I][TA]), op8(fb[cb][TB]), acc[I][c], 0, 0, 0)
+      HMM(0, 2, 0);
+      HMM(1, 2, 0);
+      HMM(0, 0, 2);
+      HMM(1, 0, 2);
+      HMM(0, 1, 1);
+      HMM(1, 1, 1);
+      HMM(0, 1, 0);
+      HMM(1, 1, 0);
+      HMM(0, 0, 1);
+      HMM(1, 0, 1);
+      HMM(0, 0, 0);
+      HMM(1, 0, 0);
+#undef HMM
+      if (c < 2) dbacc[c] += raw[c] * live;
+      split_store1(raw[c], c, buf ^ 1);
+      raw[c] = load_piece(h2, c);
+      // one MFMA, two vector instructions, ... (the split's 22 + the bias sum's 4 between the 12 MFMAs of this column tile)
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    }
+    __syncthreads();  // everyone is done with this buffer's reads and with the other buffer's writes
+  };
+
+  if (n_half > 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) raw[v] = load_piece(0, v);
+    dbacc[0] += raw[0];
+    dbacc[1] += raw[1];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) split_store1(raw[v], v, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) raw[v] = load_piece(n_half > 1 ? 1 : 0, v);
+  }
+  __syncthreads();
+  for (long h = 0; h < n_half; ++h) body(h);
+
+  // ---- write out: acc[i][c][r] on lane l = D[row 64 rg + 32 i + (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col 128 cp + 32 c + (l & 31)]
+  const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+  if (job.per_task) {
+    const int Ko = job.ldo > 0 ? job.ldo : Kp;
+    float* out = job.dW + (size_t)split * ((size_t)(Np >> 5) * Ko * 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * rg + 32 * i + (r & 3) + 8 * (r >> 2) + row_l, col = 128 * cp + 32 * c + col_l;
+          float* dst = out + (size_t)(row >> 5) * (Ko >> 2) * 128 + (row & 31) * 4 + (size_t)(col >> 2) * 128 + (col & 3);
+          *dst = (job.accumulate & NPF_WGRAD_ACCUMULATE) ? *dst + acc[i][c][r] : acc[i][c][r];
+        }
+  } else {
+    float* part = partials + J.part_off[j] + (size_t)split * ((size_t)Np * Kp + Np);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * rg + 32 * i + (r & 3) + 8 * (r >> 2) + row_l, col = 128 * cp + 32 * c + col_l;
+          part[(size_t)row * Kp + col] = acc[i][c][r];
+        }
+    // bias gradient: this lane's dZ quads 8 wave + q_ld (+ 4) summed over its points; the quad's 16 lanes differ in p_lo, p_hi
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = dbacc[v][e];
+        x += __shfl_xor(x, 1);
+        x += __shfl_xor(x, 2);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        dbacc[v][e] = x;
+      }
+      if (pt_ld == 0) *(f32x4*)(part + (size_t)Np * Kp + 4 * (8 * wave + 4 * v + q_ld)) = dbacc[v];
+    }
+  }
+}
+
 // dW[n][k] (+)= sum_s partial[s][n][k];  db[n] (+)= sum_s partial_db[s][n].
 // One float4 of the slab per thread, four independent accumulators over the splits (the sum is
 // latency-bound: each term is a separate 16-byte load from a different slab).
@@ -894,7 +1114,11 @@ extern "C" int npf_wgrad_run(const npf_wgrad_job_t* jobs, int32_t n_jobs, int32_
     bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
     x6 &= (jobs[j].accumulate & (NPF_WGRAD_F32X6 | NPF_WGRAD_BF16)) == NPF_WGRAD_F32X6;
   }
-  if (x6)
+  bool h16 = x6 && getenv("NPF_NO_WGRAD_H16") == nullptr;
+  for (int j = 0; j < n_jobs; ++j) h16 &= jobs[j].N == 256 && jobs[j].K == 256;
+  if (h16)  // 256 x 256 jobs: every operand value split once per workgroup (wgrad_h16_kernel)
+    hipLaunchKernelGGL(npf::wgrad_h16_kernel, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, J, partials);
+  else if (x6)
     hipLaunchKernelGGL(npf::wgrad_x6_kernel, dim3(n_wg), dim3(npf::kXThreads), 0, (hipStream_t)stream, J, partials);
   else if (bf16)
     hipLaunchKernelGGL(npf::wgrad_kernel<true>, dim3(n_wg), dim3(npf::kWgThreads), 0, (hipStream_t)stream, J, partials);
