@@ -145,17 +145,28 @@ class Trainer:
                         self._static_loss = self._eager_step(self._static)
                     self._graph_opt = None
                 else:
+                    # several ranks: the collective library keeps a watchdog thread that queries events; "thread_local" keeps
+                    # its calls from invalidating this thread's capture.  Should the capture fail all the same, the ranks go
+                    # on launching their steps eagerly (every rank takes the same decision: the captured work is the same).
                     self.reducer.deferred = True
                     try:
-                        with torch.cuda.graph(self._graph):
+                        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                             self._static_loss = self._forward_backward(self._static)
+                        self._graph_opt = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self._graph_opt, pool=self._graph.pool(), capture_error_mode="thread_local"):
+                            self.opt.step()
+                    except RuntimeError as e:
+                        import warnings
+
+                        warnings.warn(f"HIP-graph capture of the data-parallel step failed ({e}); launching the steps eagerly")
+                        self.use_graph, self._graph, self._graph_opt = False, None, None
+                        torch.cuda.synchronize()
                     finally:
                         self.reducer.deferred = False
-                    self._graph_opt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._graph_opt, pool=self._graph.pool()):
-                        self.opt.step()
             finally:
                 self.model.validate_inputs = was
+            if self._graph is None:
+                return self._eager_step(batch)
             self._graph_sig = sig  # (a capture records, it does not execute: this batch runs in the replay below)
         for k, v in batch.items():
             self._static[k].copy_(v)

@@ -259,18 +259,19 @@ class _TargetSideFn(torch.autograd.Function):
         W1, b1 = Ws[0], bs[0]
         W_out, b_out = Ws[-1], bs[-1]
         n_out = W_out.shape[0]
-        mid_W, mid_b = Ws[1:-1], bs[1:-1]  # the 256 -> 256 layers: x-encoder rest, latent merge, resizer, flat
+        mid_W, mid_b = Ws[1:-1], bs[1:-1]  # the F -> F layers (F = 128 or 256): x-encoder rest, latent merge, resizer, flat
+        F = mid_W[0].shape[0]
         if n_mrz:
             mid_b[n_x] = zb
         train = any(ctx.needs_input_grad)
-        imgs = _weight_images(mid_W, (1, 2) if train else (1,))
+        imgs = _weight_images(mid_W, (1, 2) if train else (1,), F)
         fw = imgs[0]
-        K_row, K_tr = task_images(K_pt, C, row=True, tr=train)
-        V_row, V_tr = task_images(V_pt, C, row=train, tr=True)
+        K_row, K_tr = task_images(K_pt, C, row=True, tr=train, width=F)
+        V_row, V_tr = task_images(V_pt, C, row=train, tr=True, width=F)
         X4 = _pad_rows4(X.detach())
-        W1p = _first_layer_matrix(W1, WIDTH)
-        pt = lambda: CH.pt_empty(B, T, WIDTH, dev)  # noqa: E731
-        prog = Program(B, tiles, per_task=True)
+        W1p = _first_layer_matrix(W1, F)
+        pt = lambda: CH.pt_empty(B, T, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=True, width=F)
         saved_acts, saved_bits = [], []
         # x-encoder: first layer in the prologue, then its 256 -> 256 layers (ReLU on all but the last, mlp.py:95-109)
         h1 = pt() if train else None
@@ -312,7 +313,7 @@ class _TargetSideFn(torch.autograd.Function):
         prog.tail = (Wo, bo, rows)
         prog.tag = "target side forward (x-encoder, attention, decoder, output layer)"
         prog.launch()
-        ctx.geom = (B, T, tiles, dx, C, float(scale), n_out)
+        ctx.geom = (B, T, tiles, dx, C, float(scale), n_out, F)
         ctx.spec = spec
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
@@ -329,7 +330,7 @@ class _TargetSideFn(torch.autograd.Function):
         n_par = 2 * (n_mid + 2)
         if g is None:
             return (None,) * (7 + n_par)
-        B, T, tiles, dx, C, scale, n_out = ctx.geom
+        B, T, tiles, dx, C, scale, n_out, F = ctx.geom
         sv = list(ctx.saved_tensors)
         X4, h1, bits_h1, Xt_enc, P, R_trgt = sv[:6]
         acts = sv[6:6 + ctx.n_acts]
@@ -338,11 +339,11 @@ class _TargetSideFn(torch.autograd.Function):
         bw, (V_row, K_tr, Wo) = rest[:n_mid], rest[n_mid:]
         dev = g.device
         g4 = g.contiguous() if n_out == 4 else torch.nn.functional.pad(g, (0, 4 - n_out)).contiguous()
-        pt = lambda: CH.pt_empty(B, T, WIDTH, dev)  # noqa: E731
+        pt = lambda: CH.pt_empty(B, T, F, dev)  # noqa: E731
         # the saved outputs by layer: x-encoder hidden layers (n_x - 1 of them), then resizer + flat (all ReLU layers)
         x_acts, x_bits = acts[:n_x - 1], bits[:n_x - 1]
         d_acts, d_bits = acts[n_x - 1:], bits[n_x - 1:]
-        prog = Program(B, tiles, per_task=True)
+        prog = Program(B, tiles, per_task=True, width=F)
         dz = [None] * n_mid  # dZ of every 256 -> 256 layer (index as in the forward: x-encoder, resizer, flat)
         # decoder layers (and the latent merge), last to first
         for i in range(n_dec - 1, -1, -1):
@@ -370,36 +371,42 @@ class _TargetSideFn(torch.autograd.Function):
         # weight / key / value gradients
         jobs, grads = [], []
         # (the first layer's fan-in zero-padded to 4, like the chain path pads skinny first layers)
-        dW1p = torch.empty((WIDTH, 4), dtype=torch.float32, device=dev)
-        db1 = torch.empty((WIDTH,), dtype=torch.float32, device=dev) if ctx.has_b[0] else None
-        jobs.append(dict(dZ=dz1, A=FN._pack(X4), N=WIDTH, K=4, dW=dW1p, db=db1))
+        dW1p = torch.empty((F, 4), dtype=torch.float32, device=dev)
+        db1 = torch.empty((F,), dtype=torch.float32, device=dev) if ctx.has_b[0] else None
+        jobs.append(dict(dZ=dz1, A=FN._pack(X4), N=F, K=4, dW=dW1p, db=db1))
         grads += [None, db1]  # (dW1 sliced out of dW1p after the launch)
         ins = [h1, *x_acts, R_trgt, *d_acts[:-1]]  # input of every 256 -> 256 layer
         for j in range(n_mid):
-            dW = torch.empty((WIDTH, WIDTH), dtype=torch.float32, device=dev)
-            db = torch.empty((WIDTH,), dtype=torch.float32, device=dev) if (ctx.has_b[1 + j] and not (n_mrz and j == n_x)) else None
-            jobs.append(dict(dZ=dz[j], A=ins[j], N=WIDTH, K=WIDTH, dW=dW, db=db))
+            dW = torch.empty((F, F), dtype=torch.float32, device=dev)
+            db = torch.empty((F,), dtype=torch.float32, device=dev) if (ctx.has_b[1 + j] and not (n_mrz and j == n_x)) else None
+            jobs.append(dict(dZ=dz[j], A=ins[j], N=F, K=F, dW=dW, db=db))
             grads += [dW, db]
         dz_out = torch.zeros(CH.pt_shape(B, T, 4), dtype=torch.float32, device=dev)
         dz_out[:, :, 0] = g4.view(B, tiles, 32, 4)
-        dWo = torch.empty((n_out, WIDTH), dtype=torch.float32, device=dev)
+        dWo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
         dbo = torch.empty((n_out,), dtype=torch.float32, device=dev) if ctx.has_b[-1] else None
-        jobs.append(dict(dZ=dz_out, A=d_acts[-1], N=n_out, K=WIDTH, dW=dWo, db=dbo))
+        jobs.append(dict(dZ=dz_out, A=d_acts[-1], N=n_out, K=F, dW=dWo, db=dbo))
         grads += [dWo, dbo]
         # (context points that do not fill their last tile: the padding rows of dK / dV are zero -- their keys have no weight)
         mk = torch.zeros if C % 32 else torch.empty
-        dK = mk(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        dV = mk(CH.pt_shape(B, C, WIDTH), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        dK = mk(CH.pt_shape(B, C, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dV = mk(CH.pt_shape(B, C, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         if dV is not None:
-            jobs.append(dict(dZ=P, A=dO, N=C, K=WIDTH, dW=dV, per_task=True, ldz=WIDTH))  # (P has 256 features per tile)
+            jobs.append(dict(dZ=P, A=dO, N=C, K=F, dW=dV, per_task=True, ldz=F))  # (P has F features per tile)
         if dK is not None:
-            jobs.append(dict(dZ=dS, A=Xt_enc, N=C, K=WIDTH, dW=dK, per_task=True, ldz=WIDTH))
+            jobs.append(dict(dZ=dS, A=Xt_enc, N=C, K=F, dW=dK, per_task=True, ldz=F))
         CH.run_wgrad(jobs, B, T, dev, tag="target side weight / key / value gradients")
         grads[0] = dW1p[:, :dx].contiguous() if dx != 4 else dW1p
         # the per-task bias of the latent merge: the sum of its dZ over the task's points (padding points carry zeros: their
         # incoming gradient is zero)
-        d_zb = FN.sum_points_pt(dz[n_x], T, WIDTH)[:, :WIDTH].contiguous() if (n_mrz and ctx.needs_input_grad[6]) else None
+        d_zb = FN.sum_points_pt(dz[n_x], T, F)[:, :F].contiguous() if (n_mrz and ctx.needs_input_grad[6]) else None
         return (None, dK, dV, None, None, None, d_zb, *grads)
+
+
+def _width_of(model) -> int:
+    """The feature width F of the model's wide layers if the x6 programs have an instance for it (128, 256), else 0."""
+    F = getattr(model, "r_dim", 0)
+    return F if (F in (128, 256) and getattr(model, "x_transf_dim", F) == F) else 0
 
 
 def _square(lins, width=WIDTH) -> bool:
@@ -413,10 +420,15 @@ def target_side_usable(model, C: int, T: int, latent_merge: bool = False) -> boo
 
     if not (ENABLED and CH.COMPUTE_DTYPE == "fp32"):
         return False
+    WIDTH = _width_of(model)
+    if not WIDTH:
+        return False
     xe, dec, att = model.x_encoder, model.decoder, getattr(model, "attender", None)
     if not isinstance(att, DotAttender) or att.kq_size != WIDTH or att.value_size != WIDTH:
         return False
-    if not (WIDTH // 2 < C <= WIDTH and T > 0):
+    # (fewer keys than half a score row: at 256 features the chain path's 32-key granularity wins; the 128-wide programs take any
+    # 1 <= C <= 128 -- the reference's 1-D experiments draw 0..50 context points)
+    if not ((WIDTH // 2 < C or (WIDTH == 128 and C >= 1)) and C <= WIDTH and T > 0):
         return False
     if not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == WIDTH and xe.output_size == WIDTH
             and not xe.is_res and not (xe.dropout_p > 0 and xe.training)):
@@ -427,7 +439,7 @@ def target_side_usable(model, C: int, T: int, latent_merge: bool = False) -> boo
     for m in (fm, rs):
         if m.is_res or (m.dropout_p > 0 and m.training):
             return False
-    if not (_square(rs.layers()) and _square([fm.to_hidden, *fm.linears]) and fm.out.in_features == WIDTH
+    if not (_square(rs.layers(), WIDTH) and _square([fm.to_hidden, *fm.linears], WIDTH) and fm.out.in_features == WIDTH
             and fm.out.out_features <= 4):
         return False
     n_mrz = int(latent_merge)
@@ -452,7 +464,7 @@ def target_side(model, X_trgt: torch.Tensor, K: CH.PTensor, V: CH.PTensor, zb: O
         params += [lin.weight, lin.bias]
     n_x = len(xe.linears) + 1
     if zb is not None:
-        params[2 * (n_x + 1):2 * (n_x + 1)] = [model.r_z_merger.weight[:, :WIDTH], None]
+        params[2 * (n_x + 1):2 * (n_x + 1)] = [model.r_z_merger.weight[:, :model.r_dim], None]
     spec = (n_x, int(zb is not None), len(rs.layers()), len(fm.linears) + 1)
     scale = 1.0 / math.sqrt(att.kq_size) if att.is_scale else 1.0
     T = X_trgt.shape[1]
@@ -482,14 +494,15 @@ class _ContextSideFn(torch.autograd.Function):
         Wr1, br1, Wr2, br2 = Ws[1 + n_x], bs[1 + n_x], Ws[2 + n_x], bs[2 + n_x]
         f_W, f_b = Ws[3 + n_x:], bs[3 + n_x:]
         h = Wr1.shape[0]
+        F = Wr2.shape[0]  # the width of every other layer: 128 or 256
         train = any(ctx.needs_input_grad)
-        Wr2p = torch.zeros((WIDTH, WIDTH), dtype=torch.float32, device=dev)  # (the h -> 256 layer as a 256-input layer:
+        Wr2p = torch.zeros((F, F), dtype=torch.float32, device=dev)  # (the h -> 256 layer as a 256-input layer:
         Wr2p[:, :h] = Wr2.detach()                                           #  the input's other registers are zero)
-        imgs = _weight_images([*x_W, Wr2p, *f_W], (1, 2) if train else (1,))
+        imgs = _weight_images([*x_W, Wr2p, *f_W], (1, 2) if train else (1,), F)
         fw = imgs[0]
         X4, Y4 = _pad_rows4(X.detach()), _pad_rows4(Y.detach())
-        pt = lambda: CH.pt_empty(B, Cn, WIDTH, dev)  # noqa: E731
-        prog = Program(B, tiles, per_task=False)
+        pt = lambda: CH.pt_empty(B, Cn, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F)
         acts, bits = [], []
         h1 = pt() if train else None
         bits_h1 = _bits(B, tiles, dev) if train else None
@@ -498,7 +511,7 @@ class _ContextSideFn(torch.autograd.Function):
             last = i == n_x - 1
             o = dict(img=fw[i], bias=x_b[i].detach() if x_b[i] is not None else None, relu=not last)
             if i == 0:
-                o.update(in_rows=X4, in_w=_first_layer_matrix(W1, WIDTH), in_b=b1.detach() if b1 is not None else None,
+                o.update(in_rows=X4, in_w=_first_layer_matrix(W1, F), in_b=b1.detach() if b1 is not None else None,
                          in_relu=True, store_in=h1, store_in_bits=bits_h1)
             if last:
                 o["store_out"] = Xc_enc
@@ -531,7 +544,7 @@ class _ContextSideFn(torch.autograd.Function):
             prog.op(**o)
         prog.tag = "context side forward (x-encoder, XY-encoder)"
         prog.launch()
-        ctx.geom = (B, Cn, tiles, dx, dy, h)
+        ctx.geom = (B, Cn, tiles, dx, dy, h, F)
         ctx.spec = spec
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
@@ -546,17 +559,17 @@ class _ContextSideFn(torch.autograd.Function):
         n_par = 2 * (1 + n_x + 2 + n_flat)
         if gK is None and gR is None:
             return (None,) * (3 + n_par)
-        B, Cn, tiles, dx, dy, h = ctx.geom
+        B, Cn, tiles, dx, dy, h, F = ctx.geom
         sv = list(ctx.saved_tensors)
         X4, Y4, h1, bits_h1, hy, bits_hy = sv[:6]
         acts, bits = sv[6:6 + ctx.n_acts], sv[6 + ctx.n_acts:6 + 2 * ctx.n_acts]
         bw = sv[6 + 2 * ctx.n_acts:]
         dev = X4.device
-        pt = lambda: CH.pt_empty(B, Cn, WIDTH, dev)  # noqa: E731
+        pt = lambda: CH.pt_empty(B, Cn, F, dev)  # noqa: E731
         x_acts, x_bits = acts[:n_x - 1], bits[:n_x - 1]
         m_act, m_bits = acts[n_x - 1], bits[n_x - 1]          # the merge's output
         f_acts, f_bits = acts[n_x:], bits[n_x:]                 # flat hidden outputs (n_flat - 1 of them)
-        prog = Program(B, tiles, per_task=False)
+        prog = Program(B, tiles, per_task=False, width=F)
         jobs, grads = [], [None] * n_par
 
         def wjob(pos, dZ, A, N, K, **kw):
@@ -580,13 +593,13 @@ class _ContextSideFn(torch.autograd.Function):
                     dz = pt()
                     o.update(mask_bits=f_bits[i], store_in=dz)
                 prog.op(**o)
-                wjob(1 + n_x + 2 + i, dz, f_in[i], WIDTH, WIDTH)
+                wjob(1 + n_x + 2 + i, dz, f_in[i], F, F)
             # the merge relu(x1 + W_r2 hy + b): its dZ is also the gradient wrt x1; then back through the h-wide first layer
             dz_m, dz_hy = pt(), pt()
             prog.op(mask_bits=m_bits, store_in=dz_m, img=bw[n_x])
             prog.op(mask_bits=bits_hy, store_in=dz_hy)
-            wjob(1 + n_x + 1, dz_m, hy, WIDTH, h, lda=WIDTH)
-            dWr1 = wjob(1 + n_x, dz_hy, FN._pack(Y4), h, 4, ldz=WIDTH)
+            wjob(1 + n_x + 1, dz_m, hy, F, h, lda=F)
+            dWr1 = wjob(1 + n_x, dz_hy, FN._pack(Y4), h, 4, ldz=F)
         # x-encoder: gradient of Xc_enc = what the attention sends back for the keys + the merge's x1 gradient
         if gK is not None or dz_m is not None:
             first = dict(in_pt=gK.contiguous(), pre_add=dz_m) if gK is not None else dict(in_pt=dz_m)
@@ -599,10 +612,10 @@ class _ContextSideFn(torch.autograd.Function):
                 else:
                     o["mask_bits"] = x_bits[i]
                 prog.op(**o)
-                wjob(1 + i, dz, x_in[i], WIDTH, WIDTH)
+                wjob(1 + i, dz, x_in[i], F, F)
             dz1 = pt()
             prog.op(mask_bits=bits_h1, store_in=dz1)
-            dW1p = wjob(0, dz1, FN._pack(X4), WIDTH, 4)
+            dW1p = wjob(0, dz1, FN._pack(X4), F, 4)
         prog.tag = "context side dgrad (XY-encoder, x-encoder)"
         prog.launch()
         CH.run_wgrad(jobs, B, Cn, dev, tag="context side weight gradients")
@@ -620,6 +633,9 @@ def context_side_usable(model, C: int) -> bool:
 
     if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or C <= 0:
         return False
+    WIDTH = _width_of(model)
+    if not WIDTH:
+        return False
     xe, xy = model.x_encoder, getattr(model, "xy_encoder", None)
     if not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == WIDTH and xe.output_size == WIDTH
             and not xe.is_res and not (xe.dropout_p > 0 and xe.training)):
@@ -630,7 +646,7 @@ def context_side_usable(model, C: int) -> bool:
     for m in (fm, rs):
         if m.is_res or (m.dropout_p > 0 and m.training):
             return False
-    if not (_square([fm.to_hidden, *fm.linears, fm.out]) and len(rs.linears) == 0 and rs.input_size <= 4
+    if not (_square([fm.to_hidden, *fm.linears, fm.out], WIDTH) and len(rs.linears) == 0 and rs.input_size <= 4
             and rs.output_size == WIDTH and rs.hidden_size % 16 == 0 and rs.hidden_size <= WIDTH):
         return False
     n_x, n_flat = len(xe.linears) + 1, len(fm.linears) + 2
@@ -651,4 +667,4 @@ def context_side(model, X_cntxt: torch.Tensor, Y_cntxt: torch.Tensor):
         X_cntxt = torch.nn.functional.pad(X_cntxt, (0, 0, 0, pad))
         Y_cntxt = torch.nn.functional.pad(Y_cntxt, (0, 0, 0, pad))
     Xc, R = _ContextSideFn.apply(X_cntxt, Y_cntxt, (len(xe.linears) + 1, len(fm.linears) + 2), *params)
-    return CH.PTensor(Xc, Cn, WIDTH), CH.PTensor(R, Cn, WIDTH)
+    return CH.PTensor(Xc, Cn, model.r_dim), CH.PTensor(R, Cn, model.r_dim)

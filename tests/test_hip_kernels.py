@@ -406,6 +406,47 @@ def test_wgrad_split_bf16_products_equal_fp32():
             assert float(((got - ref).abs() / mag).max()) <= 2e-6, (x6, N, K)
 
 
+def test_wgrad_h16_split_once_kernel_matches_float64(monkeypatch):
+    """wgrad_h16_kernel (256 x 256 jobs: every operand value split once per workgroup, half tiles of 16 points, transposed LDS
+    reads, v_mfma_f32_32x32x16_bf16): dW, db and per-task outputs against float64 at fp32 summation noise -- one tile, odd tile
+    counts, several jobs per launch, blocks of 512-wide tensors (strided tiles), accumulation -- and against the kernel it
+    replaces (NPF_NO_WGRAD_H16=1) to the same noise."""
+    CH, FN = _mods()
+    g = torch.Generator().manual_seed(53)
+    spread = lambda *sh: torch.randn(*sh, generator=g) * 10.0 ** (4 * torch.rand(*sh, generator=g) - 2)  # noqa: E731
+    for n_tasks, pts, N, K, n_jobs in ((1, 32, 256, 256, 1), (3, 70, 256, 256, 3), (2, 97, 512, 512, 1), (5, 33, 256, 512, 2)):
+        ops = [(spread(n_tasks, pts, N), spread(n_tasks, pts, K)) for _ in range(n_jobs)]
+        res = {}
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("NPF_NO_WGRAD_H16", "1")
+            else:
+                monkeypatch.delenv("NPF_NO_WGRAD_H16", raising=False)
+            dWs = [torch.zeros(N, K, device=DEV) for _ in ops]
+            dbs = [torch.zeros(N, device=DEV) for _ in ops]
+            CH.run_wgrad([dict(dZ=FN.pack_pt(dz.to(DEV)), A=FN.pack_pt(a.to(DEV)), N=N, K=K, dW=dW, db=db)
+                          for (dz, a), dW, db in zip(ops, dWs, dbs)], n_tasks, pts, DEV)
+            res[old] = ([d.cpu().double() for d in dWs], [d.cpu().double() for d in dbs])
+        for j, (dz, a) in enumerate(ops):
+            ref = torch.einsum("bpn,bpk->nk", dz.double(), a.double())
+            mag = torch.einsum("bpn,bpk->nk", dz.double().abs(), a.double().abs())
+            for old in (False, True):
+                assert float(((res[old][0][j] - ref).abs() / mag).max()) <= 2e-6, (old, n_tasks, pts, N, K, j)
+                assert float((res[old][1][j] - dz.double().sum((0, 1))).abs().max()) <= 2e-6 * float(dz.double().abs().sum((0, 1)).max())
+    # per-task outputs (key / value gradients), accumulated into
+    monkeypatch.delenv("NPF_NO_WGRAD_H16", raising=False)
+    for n_tasks, pts in ((3, 130), (1, 16), (2, 1024)):
+        dz, a = spread(n_tasks, pts, 256), spread(n_tasks, pts, 256)
+        ref = torch.einsum("bpn,bpk->bnk", dz.double(), a.double())
+        mag = torch.einsum("bpn,bpk->bnk", dz.double().abs(), a.double().abs())
+        base = torch.randn(n_tasks, 256, 256, generator=g)
+        out = FN.pack_pt(base.to(DEV)).contiguous()
+        CH.run_wgrad([dict(dZ=FN.pack_pt(dz.to(DEV)), A=FN.pack_pt(a.to(DEV)), N=256, K=256, dW=out, per_task=True, accumulate=True)],
+                     n_tasks, pts, DEV)
+        got = FN.unpack_pt(out, 256, 256).cpu().double() - base.double()
+        assert float(((got - ref).abs() / (mag + base.double().abs())).max()) <= 2e-6, (n_tasks, pts)
+
+
 def test_mlp_x6_stack_forward_and_backward_match_float64():
     """npf_mlp_x6_run (csrc/mlp_x6_kernel.hip): a stack of 256 -> 256 layers with the fp32 products on the bf16 pipe (three exact
     bf16 terms per operand, six cross products).  Forward values, the input gradient and every dW / db against a float64

@@ -100,24 +100,28 @@ def _target_side_f64(model, X, K, V):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3], ids=["16_points_per_wave", "32_points_per_wave", "8_waves_one_slab_ring"])
-@pytest.mark.parametrize("B,C,T,L,dx,dy", [(2, 256, 64, 4, 1, 2), (3, 200, 96, 2, 2, 1), (1, 129, 32, 1, 1, 2), (2, 250, 70, 2, 1, 2),
-                                           (3, 256, 288, 1, 1, 2)])
-def test_fused_target_side_matches_float64(B, C, T, L, dx, dy, variant, monkeypatch):
+@pytest.mark.parametrize("B,C,T,L,dx,dy,r", [(2, 256, 64, 4, 1, 2, 256), (3, 200, 96, 2, 2, 1, 256), (1, 129, 32, 1, 1, 2, 256),
+                                             (2, 250, 70, 2, 1, 2, 256), (3, 256, 288, 1, 1, 2, 256),
+                                             # r = 128: the reference's default width (base.py:104-117), few context points
+                                             (3, 128, 64, 2, 1, 2, 128), (2, 37, 70, 4, 1, 2, 128), (4, 5, 33, 1, 2, 1, 128)])
+def test_fused_target_side_matches_float64(B, C, T, L, dx, dy, r, variant, monkeypatch):
     from npf_gwwaveform_amd import chain as CH
     from npf_gwwaveform_amd import functional as FN
     from npf_gwwaveform_amd import x6
 
-    monkeypatch.setattr(x6, "VARIANT", variant)  # (both instances of the 256-wide program kernel, whatever the default is)
+    if r == 128 and variant != 1:
+        pytest.skip("one instance at 128 features")
+    monkeypatch.setattr(x6, "VARIANT", variant)  # (every instance of the 256-wide program kernel, whatever the default is)
 
-    model = _build(L=L, dx=dx, dy=dy, seed=B * 7 + C)
+    model = _build(r=r, L=L, dx=dx, dy=dy, seed=B * 7 + C)
     assert x6.target_side_usable(model, C, T)
     g = torch.Generator().manual_seed(C + T)
     X = torch.rand(B, T, dx, generator=g) * 2 - 1
-    K = torch.randn(B, C, 256, generator=g) * 0.5
-    V = torch.randn(B, C, 256, generator=g) * 0.5
+    K = torch.randn(B, C, r, generator=g) * 0.5
+    V = torch.randn(B, C, r, generator=g) * 0.5
     w = torch.randn(B, T, 2 * dy, generator=g)
     Kd, Vd = K.to(DEV).requires_grad_(True), V.to(DEV).requires_grad_(True)
-    rows = x6.target_side(model, X.to(DEV), CH.PTensor(FN.pack_pt(Kd), C, 256), CH.PTensor(FN.pack_pt(Vd), C, 256))
+    rows = x6.target_side(model, X.to(DEV), CH.PTensor(FN.pack_pt(Kd), C, r), CH.PTensor(FN.pack_pt(Vd), C, r))
     assert tuple(rows.shape) == (B, T, 2 * dy)
     (rows * w.to(DEV)).sum().backward()
     Kr, Vr = K.double().requires_grad_(True), V.double().requires_grad_(True)
@@ -168,27 +172,30 @@ def _context_side_f64(model, X, Y):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3], ids=["16_points_per_wave", "32_points_per_wave", "8_waves_one_slab_ring"])
-@pytest.mark.parametrize("B,C,L,dx,dy", [(2, 256, 4, 1, 2), (3, 64, 2, 2, 1), (1, 32, 1, 1, 3), (2, 45, 2, 1, 2), (5, 96, 1, 1, 2)])
-def test_fused_context_side_matches_float64(B, C, L, dx, dy, variant, monkeypatch):
+@pytest.mark.parametrize("B,C,L,dx,dy,r", [(2, 256, 4, 1, 2, 256), (3, 64, 2, 2, 1, 256), (1, 32, 1, 1, 3, 256), (2, 45, 2, 1, 2, 256),
+                                           (5, 96, 1, 1, 2, 256), (3, 50, 2, 1, 2, 128), (2, 128, 4, 2, 1, 128)])
+def test_fused_context_side_matches_float64(B, C, L, dx, dy, r, variant, monkeypatch):
     from npf_gwwaveform_amd import functional as FN
     from npf_gwwaveform_amd import x6
 
+    if r == 128 and variant != 1:
+        pytest.skip("one instance at 128 features")
     monkeypatch.setattr(x6, "VARIANT", variant)
 
-    model = _build(L=L, dx=dx, dy=dy, seed=B * 11 + C)
+    model = _build(r=r, L=L, dx=dx, dy=dy, seed=B * 11 + C)
     assert x6.context_side_usable(model, C)
     g = torch.Generator().manual_seed(C + L)
     X = torch.rand(B, C, dx, generator=g) * 2 - 1
     Y = torch.randn(B, C, dy, generator=g)
-    wk, wr = torch.randn(B, C, 256, generator=g), torch.randn(B, C, 256, generator=g)
+    wk, wr = torch.randn(B, C, r, generator=g), torch.randn(B, C, r, generator=g)
     Xc, R = x6.context_side(model, X.to(DEV), Y.to(DEV))
-    (FN.unpack_pt(Xc.t, C, 256) * wk.to(DEV)).sum().backward(retain_graph=True)
+    (FN.unpack_pt(Xc.t, C, r) * wk.to(DEV)).sum().backward(retain_graph=True)
     gk_only = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    (FN.unpack_pt(R.t, C, 256) * wr.to(DEV)).sum().backward()
+    (FN.unpack_pt(R.t, C, r) * wr.to(DEV)).sum().backward()
     Xc_r, R_r, P = _context_side_f64(model, X.double(), Y.double())
     ((Xc_r * wk.double()).sum() + (R_r * wr.double()).sum()).backward()
-    assert_close(FN.unpack_pt(Xc.t, C, 256), Xc_r, tol=1e-5, what="Xc_enc")
-    assert_close(FN.unpack_pt(R.t, C, 256), R_r, tol=1e-5, what="R")
+    assert_close(FN.unpack_pt(Xc.t, C, r), Xc_r, tol=1e-5, what="Xc_enc")
+    assert_close(FN.unpack_pt(R.t, C, r), R_r, tol=1e-5, what="R")
     assert set(gk_only) == {k for k in P if k.startswith("x_encoder")}  # (a gradient for the keys alone stays in the x-encoder)
     for k, p in model.named_parameters():
         if k.startswith("decoder"):
