@@ -11,7 +11,7 @@
 // Layout = the chain kernel's: a wave owns 16 points (half a PT32 tile), block b / element e of lane (p, g) = feature
 // 16 b + 4 g + e of point p; a workgroup = 4 waves = 2 tiles, two workgroups per CU.  Weights stream L2 -> LDS by LDS-DMA in
 // slabs of 16 output rows x 3 terms (24 KiB) through a three-slot ring: slab S + 2 is in flight while slab S multiplies, one
-// counted s_waitcnt vmcnt + one barrier per slab.  Measured standalone (tools/experiments/x6_mlp_probe.hip): 8 layers over
+// counted s_waitcnt vmcnt + one barrier per slab.  Measured standalone (a probe of round 2, see tools/experiments/README.md): 8 layers over
 // 1 M points 4.75 ms = 231 TF/s fp32-equivalent, against 131 TF/s of the fp32 chain kernel on the same stack.
 //
 // Tried, not kept: the compiler waits for vmcnt(0) -- draining the slab ring -- once per layer for the bias load and once at

@@ -155,15 +155,6 @@ if __name__ == "__main__":
             CH.DEBUG_ABLATE = bits
             chain_case_bf16(f"bf16 ablate[{name}] 8 x linear 256->256", 1024, T, [(256, 256)] * 8)
         CH.DEBUG_ABLATE = 0
-    if "bf16ab" in which:  # the two bf16 chain interpreters side by side (FORCE_WG = 4: chain16_kernel.hip)
-        for mode, name in [(0, "16 pts/wave"), (4, "chain16")]:
-            CH.FORCE_WG = mode
-            chain_case_bf16(f"[{name}] bf16 8 x linear 256->256, store last", 1024, T, [(256, 256)] * 8)
-            chain_case_bf16(f"[{name}] bf16 8 x linear 256->256, no relu, store last", 1024, T, [(256, 256)] * 8, relu=False)
-            chain_case_bf16(f"[{name}] bf16 8 x linear 256->256, store every layer (PT16)", 1024, T, [(256, 256)] * 8, store="pt16")
-            chain_case_bf16(f"[{name}] bf16 1 x linear 256->256", 1024, T, [(256, 256)])
-            chain_case_bf16(f"[{name}] bf16 8 x linear 128->128", 1024, T, [(128, 128)] * 8)
-        CH.FORCE_WG = 0
     if "decode" in which:
         # BASELINE config 5 per GPU: decoder r=512, L=4, T=4096, 512 tasks (4096 / 8 GPUs)
         chain_case("decode c5: 6 x 512->512 + 512->4, B=128 T=4096", 128, 4096, [(512, 512)] * 6 + [(512, 4)])
