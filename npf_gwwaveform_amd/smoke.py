@@ -11,14 +11,20 @@ import torch
 
 
 def run() -> None:
+    """Two small train steps against the CPU oracle: r = 64 (chain kernel) and the flagship width r = 256 with 130 context points
+    (the fused x6 programs and the split weight-gradient kernels of BASELINE configs 2 / 4)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
+    _one(64, 2, 4, 64, 96)
+    _one(256, 2, 2, 130, 64)
+
+
+def _one(r, L, B, C, T) -> None:
     import npf_gwwaveform_amd as A
     from oracle import npf_oracle as O
 
     dev = "cuda:0"
-    r, L, B, C, T = 64, 2, 4, 64, 96
     cfg = O.OracleConfig(kind="AttnCNP", x_dim=1, y_dim=2, r_dim=r)
     params = O.perturb_biases(O.init_params(cfg, seed=3, n_layers_xy=L, n_layers_dec=L), seed=4)
     g = torch.Generator().manual_seed(0)
@@ -51,7 +57,7 @@ def run() -> None:
     e_scale = rel(out[0].base_dist.scale, ref["scale"])
     e_loss = abs(loss.item() - ref_loss.item()) / abs(ref_loss.item())
     e_grad = max(rel(p.grad, ref_p[k].grad) for k, p in model.named_parameters())
-    print(f"smoke: loc {e_loc:.2e} scale {e_scale:.2e} loss {e_loss:.2e} grads {e_grad:.2e} (rel, vs CPU oracle)")
+    print(f"smoke r={r}: loc {e_loc:.2e} scale {e_scale:.2e} loss {e_loss:.2e} grads {e_grad:.2e} (rel, vs CPU oracle)")
     assert e_loc <= 1e-5 and e_scale <= 1e-5 and e_loss <= 1e-5 and e_grad <= 1e-4, "HIP path disagrees with the oracle"
 
 
