@@ -192,6 +192,8 @@ def decode_rows_usable(mod, x1: torch.Tensor, x2: torch.Tensor) -> bool:
     fm, rs = mod.flat_module, mod.resizer
     if F not in (128, 256, 512) or x2.shape[-1] != F or x1.shape[:-1] != x2.shape[:-1] or fm.is_res or rs.is_res:
         return False
+    if any(m.dropout_p > 0 and m.training for m in (fm, rs)):  # (active dropout: the chain path draws and applies the masks)
+        return False
     if not (_square(rs.layers(), F) and _square([fm.to_hidden, *fm.linears], F) and fm.out.in_features == F
             and fm.out.out_features <= 4):
         return False
