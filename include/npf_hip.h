@@ -193,6 +193,9 @@ typedef struct npf_wgrad_job {
  * below 2^-26 of a product, i.e. under fp32 rounding; same operands, same result to summation-order noise, 6/16 of
  * the v_mfma_f32_16x16x4_f32 time (csrc/wgrad_kernel.hip, wgrad_x6_kernel). */
 #define NPF_WGRAD_F32X6 16
+/* with NPF_WGRAD_F32X6: keep wgrad_x6_kernel (every wave splits the fragments it reads) for this launch; default for launches whose
+ * jobs are all 256 x 256 is wgrad_h16_kernel (every operand value split once per workgroup).  An A/B switch. */
+#define NPF_WGRAD_NO_H16 32
 
 #define NPF_MAX_WGRAD_JOBS 16
 /* Runs up to NPF_MAX_WGRAD_JOBS jobs over the same points in ONE launch (+ one reduce). */

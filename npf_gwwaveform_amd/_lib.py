@@ -55,6 +55,7 @@ class NpfWgradJob(C.Structure):
 
 NPF_MAX_WGRAD_JOBS = 16
 WGRAD_F32X6 = 16              # npf_wgrad_job_t.accumulate bit: fp32 contraction as six bf16 products per term (NPF_WGRAD_F32X6)
+WGRAD_NO_H16 = 32             # ... and keep wgrad_x6_kernel for 256 x 256 jobs too (NPF_WGRAD_NO_H16, an A/B switch)
 
 
 class NpfWprepJob(C.Structure):

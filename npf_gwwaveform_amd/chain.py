@@ -46,6 +46,9 @@ FUSE_STORES = os.environ.get("NPF_NO_FUSED_STORE", "0") != "1"  # bf16 mode: STO
 # kernel to fp32 summation-order noise, at 6/16 of its matrix-pipe time).  NPF_NO_WGRAD_X6=1: the native fp32 kernel.
 WGRAD_X6 = os.environ.get("NPF_NO_WGRAD_X6", "0") != "1"
 X6_NARROW_NATIVE = os.environ.get("NPF_X6_ALL", "0") != "1"  # narrow jobs of an fp32 launch keep the fp32-MFMA kernel
+# launches whose jobs are all 256 x 256 run on wgrad_h16_kernel (every operand value split once per workgroup);
+# NPF_NO_WGRAD_H16=1: wgrad_x6_kernel for those too
+WGRAD_H16 = os.environ.get("NPF_NO_WGRAD_H16", "0") != "1"
 
 
 # Compute mode of the MLP chains ("fp32" | "bf16"), see set_compute_dtype.  In "bf16" every chain made only
@@ -481,7 +484,7 @@ def _launch_wgrad(jobs: Sequence[dict], n_tasks: int, pts: int, device, x6: bool
             # bit 1: bf16 products (bf16 compute mode: every weight / key / value gradient of the step)
             arr[j].accumulate = (int(jb.get("accumulate", False)) | (2 if COMPUTE_DTYPE == "bf16" else 0)
                                  | (4 if z16 else 0) | (8 if a16 else 0)
-                                 | (L.WGRAD_F32X6 if x6 else 0))
+                                 | (L.WGRAD_F32X6 if x6 else 0) | (L.WGRAD_NO_H16 if (x6 and not WGRAD_H16) else 0))
         nbytes = lib.npf_wgrad_partials_bytes(arr, len(chunk), n_tasks, tiles_of(pts))
         if nbytes < 0:
             raise RuntimeError("npf_wgrad_partials_bytes: invalid wgrad jobs")

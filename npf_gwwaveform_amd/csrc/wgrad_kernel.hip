@@ -13,8 +13,6 @@
 // registers, streams its tiles by LDS-DMA through a double-buffered, XOR-
 // swizzled LDS image (one barrier per tile) and writes one partial; a second tiny kernel sums
 // the partials of the workgroups that split the points (deterministic, no atomics).
-#include <cstdlib>
-
 #include "npf_common.hpp"
 
 namespace npf {
@@ -747,7 +745,7 @@ __global__ __launch_bounds__(kXThreads, 1) void wgrad_x6_kernel(const WgradJobs 
 // per half tile.  Measured (config 2, target-side launch: nine 256 x 256 jobs over 262 144 points + its narrow jobs and reduces):
 // 1.79 ms with wgrad_x6_kernel -> 1.50 ms; a first version without the software pipeline (split, then reads, then MFMAs) 1.92.
 // The transposed reads are the clang builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16: hipcc places the waits and builds the
-// 8-element operands without register copies; as inline asm the two halves of an operand cost four v_mov each).  NPF_NO_WGRAD_H16=1
+// 8-element operands without register copies; as inline asm the two halves of an operand cost four v_mov each).  NPF_WGRAD_NO_H16 on a job
 // keeps wgrad_x6_kernel.  LDS rows are 576 bytes apart: the transposed reads (rows q, q + 1 .. of two 16-feature blocks per 32-lane
 // half) and the row writes (lanes dealt as 4 points x 4 feature quads per 16 lanes) are both bank-conflict free.
 constexpr int kHRow = 576;                       // bytes between the rows (points) of a term image
@@ -1114,8 +1112,8 @@ extern "C" int npf_wgrad_run(const npf_wgrad_job_t* jobs, int32_t n_jobs, int32_
     bf16 &= (jobs[j].accumulate & NPF_WGRAD_BF16) != 0;
     x6 &= (jobs[j].accumulate & (NPF_WGRAD_F32X6 | NPF_WGRAD_BF16)) == NPF_WGRAD_F32X6;
   }
-  bool h16 = x6 && getenv("NPF_NO_WGRAD_H16") == nullptr;
-  for (int j = 0; j < n_jobs; ++j) h16 &= jobs[j].N == 256 && jobs[j].K == 256;
+  bool h16 = x6;
+  for (int j = 0; j < n_jobs; ++j) h16 &= jobs[j].N == 256 && jobs[j].K == 256 && !(jobs[j].accumulate & NPF_WGRAD_NO_H16);
   if (h16)  // 256 x 256 jobs: every operand value split once per workgroup (wgrad_h16_kernel)
     hipLaunchKernelGGL(npf::wgrad_h16_kernel, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, J, partials);
   else if (x6)

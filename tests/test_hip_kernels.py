@@ -410,7 +410,7 @@ def test_wgrad_h16_split_once_kernel_matches_float64(monkeypatch):
     """wgrad_h16_kernel (256 x 256 jobs: every operand value split once per workgroup, half tiles of 16 points, transposed LDS
     reads, v_mfma_f32_32x32x16_bf16): dW, db and per-task outputs against float64 at fp32 summation noise -- one tile, odd tile
     counts, several jobs per launch, blocks of 512-wide tensors (strided tiles), accumulation -- and against the kernel it
-    replaces (NPF_NO_WGRAD_H16=1) to the same noise."""
+    replaces (chain.WGRAD_H16 = False) to the same noise."""
     CH, FN = _mods()
     g = torch.Generator().manual_seed(53)
     spread = lambda *sh: torch.randn(*sh, generator=g) * 10.0 ** (4 * torch.rand(*sh, generator=g) - 2)  # noqa: E731
@@ -418,10 +418,7 @@ def test_wgrad_h16_split_once_kernel_matches_float64(monkeypatch):
         ops = [(spread(n_tasks, pts, N), spread(n_tasks, pts, K)) for _ in range(n_jobs)]
         res = {}
         for old in (False, True):
-            if old:
-                monkeypatch.setenv("NPF_NO_WGRAD_H16", "1")
-            else:
-                monkeypatch.delenv("NPF_NO_WGRAD_H16", raising=False)
+            monkeypatch.setattr(CH, "WGRAD_H16", not old)
             dWs = [torch.zeros(N, K, device=DEV) for _ in ops]
             dbs = [torch.zeros(N, device=DEV) for _ in ops]
             CH.run_wgrad([dict(dZ=FN.pack_pt(dz.to(DEV)), A=FN.pack_pt(a.to(DEV)), N=N, K=K, dW=dW, db=db)
@@ -434,7 +431,7 @@ def test_wgrad_h16_split_once_kernel_matches_float64(monkeypatch):
                 assert float(((res[old][0][j] - ref).abs() / mag).max()) <= 2e-6, (old, n_tasks, pts, N, K, j)
                 assert float((res[old][1][j] - dz.double().sum((0, 1))).abs().max()) <= 2e-6 * float(dz.double().abs().sum((0, 1)).max())
     # per-task outputs (key / value gradients), accumulated into
-    monkeypatch.delenv("NPF_NO_WGRAD_H16", raising=False)
+    monkeypatch.setattr(CH, "WGRAD_H16", True)
     for n_tasks, pts in ((3, 130), (1, 16), (2, 1024)):
         dz, a = spread(n_tasks, pts, 256), spread(n_tasks, pts, 256)
         ref = torch.einsum("bpn,bpk->bnk", dz.double(), a.double())
