@@ -21,7 +21,20 @@ N_CASES = int(os.environ.get("NPF_STRESS", "0"))
 DTYPE = os.environ.get("NPF_STRESS_DTYPE", "fp32")
 
 
+FUSED_ONLY = os.environ.get("NPF_STRESS_FUSED", "0") == "1"  # draw only what the fused x6 sides take (x6.py)
+
+
 def _random_case(rng: random.Random) -> dict:
+    if FUSED_ONLY:
+        # attentive models with scaled-dot attention at the widths the x6 programs have instances for, any point counts
+        kind = rng.choice(["AttnCNP", "AttnLNP"])
+        r = rng.choice([128, 256])
+        case = dict(kind=kind, r=r, L_xy=rng.randint(1, 4), L_dec=rng.randint(1, 4), dx=rng.randint(1, 3), dy=rng.randint(1, 2),
+                    B=rng.randint(1, 5), C=rng.choice([1, 2, 17, 31, 32, 33, 64, 100, 127, 128, 129, 200, 255, 256]),
+                    T=rng.choice([1, 3, 16, 31, 32, 33, 65, 128, 200, 257]), is_heteroskedastic=rng.random() < 0.8)
+        if kind == "AttnLNP":
+            case.update(n_z=rng.choice([1, 1, 2]), is_q_zCct=rng.random() < 0.5)
+        return case
     kind = rng.choice(["CNP", "LNP", "AttnCNP", "AttnLNP"])
     r = rng.choice([8, 12, 20, 32, 40, 64, 72, 96, 100, 128, 160, 200, 256])
     case = dict(kind=kind, r=r, L_xy=rng.randint(1, 3), L_dec=rng.randint(1, 4), dx=rng.randint(1, 3), dy=rng.randint(1, 3),
