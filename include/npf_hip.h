@@ -383,12 +383,15 @@ typedef struct npf_x6_op {
   int32_t softmax_n;   /* 0 = no softmax */
   float softmax_scale;
   float sbwd_scale;
-  int32_t reserved[2]; /* [0]: NPF_X6_IN_RM | NPF_X6_ADD_RM; [1]: 0 */
+  int32_t reserved[2]; /* [0]: op flags (NPF_X6_IN_RM ...); [1]: 0 */
 } npf_x6_op_t;
 /* op flags (reserved[0]): in_pt / addend are ROW-MAJOR [n_tasks][pts_per_task][F] tensors -- what the reference's decode(X_trgt_enc,
  * R_trgt) is handed (npf/neuralproc/base.py:327) -- read without a layout pass (inference inputs: no gradient flows into them) */
 #define NPF_X6_IN_RM 1
 #define NPF_X6_ADD_RM 2
+/* npf_b16_run only: store_in / store_out take the fp32 value as a PT32 tensor (default there: bf16(value) as a PT16 tensor) */
+#define NPF_X6_STORE_IN_F32 4
+#define NPF_X6_STORE_OUT_F32 8
 /* 256-feature programs, the library's choice of kernel instance (npf_x6_run_ex variant 0): 1 = 16 points per wave, four waves per
  * workgroup, two workgroups per CU; 2 = 32 points per wave (one wave per SIMD, every weight fragment feeds twice the matrix
  * instructions); 3 = 16 points per wave, EIGHT waves per workgroup sharing one slab ring (a CU streams every slab once) */
@@ -411,6 +414,23 @@ int npf_x6_run(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const 
  *   tr_img  [n_tasks][3][F][F] bf16: W[n = feature][k = point]   (attn . V, dq = K^T dS), points >= pts are zero columns;
  * both k-permuted like npf_cast_bf16_weights.  pts <= F points per task.  Either destination may be NULL. */
 int npf_x6_task_images(const float *src, int32_t n_tasks, int32_t pts, int32_t width, void *row_img, void *tr_img, void *stream);
+
+/* ---- b16 programs: the same programs in the bf16 compute mode (BASELINE config 3) ------------------------------------------
+ * npf_x6_op_t programs of width 128 or 256 with ONE bf16 product per multiply, fp32 accumulation: the input of every multiply is
+ * rounded to bf16 (nearest even), w_img is a ONE-term image [F][F] bf16 (npf_prepare_weights kinds 1 / 2; npf_b16_task_images for
+ * the task's keys / values), bias / addend / ReLU / softmax in fp32 -- the arithmetic of the bf16 chain instance
+ * (npf/architectures/mlp.py:95-109, attention.py:129-164 with the rounding points DESIGN.md 4 lists).  Differences to npf_x6_run:
+ *   store_in / store_out  <- bf16(cur) as a PT16 tensor [tiles][F/8][32][8] (see NPF_F_P16) -- what only the weight-gradient launch
+ *                            reads -- unless NPF_X6_STORE_IN_F32 / NPF_X6_STORE_OUT_F32 asks for the fp32 value as a PT32 tensor;
+ *   sbwd_p                =  a PT16 tensor (the saved probabilities are bf16 values);
+ *   in_rows prologue / the F -> 4 layer behind the program: fp32 FMAs; the caller hands bf16-ROUNDED rows and matrices, the
+ *                            F -> 4 layer rounds its input itself;
+ *   mask (PT32), row-major operands: not available.
+ * Whole tiles only (pts_per_task = 32 tiles_per_task).  variant: 0 = the library's choice, 1 = 16 points per wave, 2 = 32. */
+int npf_b16_run(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const float *out_b, float *out_rows, int32_t n_tasks,
+                int32_t tiles_per_task, int32_t per_task, int32_t width, int32_t variant, void *stream);
+/* npf_x6_task_images with the rounded value alone: row_img / tr_img [n_tasks][F][F] bf16. */
+int npf_b16_task_images(const float *src, int32_t n_tasks, int32_t pts, int32_t width, void *row_img, void *tr_img, void *stream);
 
 int npf_version(void);
 

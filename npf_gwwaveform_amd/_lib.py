@@ -75,6 +75,7 @@ class NpfX6Layer(C.Structure):
 
 NPF_X6_MAX_OPS = 12
 X6_IN_RM, X6_ADD_RM = 1, 2  # npf_x6_op_t.reserved[0]: in_pt / addend are row-major [n_tasks][pts][F] tensors
+X6_STORE_IN_F32, X6_STORE_OUT_F32 = 4, 8  # npf_b16_run: that store takes the fp32 value (PT32) instead of bf16(value) (PT16)
 
 
 class NpfX6Op(C.Structure):
@@ -114,6 +115,8 @@ SIGNATURES = {
     "npf_x6_run": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "npf_x6_run_ex": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "npf_x6_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
+    "npf_b16_run": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "npf_b16_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "npf_version": (C.c_int, []),
 }
 

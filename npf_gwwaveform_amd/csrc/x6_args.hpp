@@ -1,0 +1,105 @@
+// What the two program interpreters share (csrc/x6_kernel.hip: fp32 results from three-term bf16 splits; csrc/b16_kernel.hip: the
+// bf16 compute mode, one bf16 term): the launch argument block, its validation, and the small device helpers.
+#pragma once
+#include "npf_common.hpp"
+
+namespace npf {
+
+typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned xp_u32x4 __attribute__((ext_vector_type(4)));
+
+struct XpArgs {
+  npf_x6_op_t op[NPF_X6_MAX_OPS];
+  const char* mm_img[NPF_X6_MAX_OPS];  // the multiplies of the program in order (what the slab stream walks)
+  int64_t mm_stride[NPF_X6_MAX_OPS];
+  const float* out_w;
+  const float* out_b;
+  float* out_rows;
+  int32_t n_ops, n_mm;
+  int32_t total_tiles, tiles_per_task;
+  int32_t wgs_per_task;  // 0: tiles dealt flat
+  int32_t xcd_remap;     // the workgroups of a task on one XCD (grid a multiple of 8)
+  int32_t pts_per_task;  // valid points per task (row-major operands; PT32 operands are padded to whole tiles)
+};
+
+__device__ __forceinline__ void xp_dma16(const void* src, void* lds_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned xp_cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// sum / max over the four lanes (g = 0..3) that share a point
+__device__ __forceinline__ float xp_sum4(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float xp_max4(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
+// Validates a program and fills ``a`` (everything but the grid geometry: wgs_per_task, xcd_remap).  ``flag_mask``: the op flags
+// (reserved[0]) this interpreter knows; ``bits_max_width``: the widest program that may carry ReLU-bit / softmax operands.
+inline int xp_fill_args(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
+                        int32_t n_tasks, int32_t tiles_per_task, int32_t pts_per_task, int32_t per_task, int32_t width,
+                        int32_t flag_mask, int32_t bits_max_width, XpArgs& a) {
+  if (!ops || n_ops <= 0 || n_ops > NPF_X6_MAX_OPS || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
+  if (pts_per_task <= 0 || pts_per_task > tiles_per_task * 32 || pts_per_task <= (tiles_per_task - 1) * 32) return NPF_EINVAL;
+  if ((out_rows != nullptr) != (out_w != nullptr) || (out_b != nullptr && out_rows == nullptr)) return NPF_EINVAL;
+  if ((((uintptr_t)out_w) | ((uintptr_t)out_rows)) & 15) return NPF_EINVAL;
+  if (((uintptr_t)out_b) & 3) return NPF_EINVAL;
+  a.n_mm = 0;
+  bool have_cur = false;
+  for (int l = 0; l < n_ops; ++l) {
+    const npf_x6_op_t& o = ops[l];
+    if ((o.in_pt != nullptr) && (o.in_rows != nullptr)) return NPF_EINVAL;
+    if ((o.in_rows != nullptr) != (o.in_w != nullptr) || (o.in_b != nullptr && o.in_rows == nullptr)) return NPF_EINVAL;
+    if (o.in_rows != nullptr && (o.in_n <= 0 || o.in_n > width || (o.in_n & 15))) return NPF_EINVAL;
+    if (o.in_pt != nullptr || o.in_rows != nullptr) have_cur = true;
+    if (!have_cur) return NPF_EINVAL;  // (the first op must bring an input)
+    if (o.reserved[0] & ~flag_mask) return NPF_EINVAL;
+    if (((o.reserved[0] & NPF_X6_IN_RM) && !o.in_pt) || ((o.reserved[0] & NPF_X6_ADD_RM) && !o.addend)) return NPF_EINVAL;
+    if ((((uintptr_t)o.in_pt) | ((uintptr_t)o.in_rows) | ((uintptr_t)o.in_w) | ((uintptr_t)o.in_b) | ((uintptr_t)o.pre_add) |
+         ((uintptr_t)o.mask) | ((uintptr_t)o.sbwd_p) | ((uintptr_t)o.store_in) | ((uintptr_t)o.w_img) | ((uintptr_t)o.addend) |
+         ((uintptr_t)o.store_out)) & 15)
+      return NPF_EINVAL;
+    if ((((uintptr_t)o.mask_bits) | ((uintptr_t)o.store_in_bits) | ((uintptr_t)o.store_bits)) & 7) return NPF_EINVAL;
+    // (a lane's ReLU bits are one 64-bit word: 16 blocks of 4 features; wider programs are inference programs)
+    if (width > bits_max_width && (o.mask_bits || o.store_in_bits || o.store_bits || o.sbwd_p || o.softmax_n)) return NPF_EINVAL;
+    if (((uintptr_t)o.bias) & 3) return NPF_EINVAL;
+    if ((o.w_task_stride & 15) || o.w_task_stride < 0 || o.bias_task_stride < 0) return NPF_EINVAL;
+    if ((o.w_task_stride != 0 || o.bias_task_stride != 0) && !per_task) return NPF_EINVAL;
+    if (o.softmax_n < 0 || o.softmax_n > width) return NPF_EINVAL;
+    if (o.w_img == nullptr && (o.bias || o.addend || o.store_out || o.store_bits || o.relu || o.softmax_n)) return NPF_EINVAL;
+    a.op[l] = o;
+    if (o.w_img != nullptr) {
+      a.mm_img[a.n_mm] = (const char*)o.w_img;
+      a.mm_stride[a.n_mm] = o.w_task_stride;
+      ++a.n_mm;
+    }
+  }
+  for (int l = n_ops; l < NPF_X6_MAX_OPS; ++l) a.op[l] = ops[0];
+  for (int j = a.n_mm; j < NPF_X6_MAX_OPS; ++j) {
+    a.mm_img[j] = a.n_mm ? a.mm_img[0] : nullptr;
+    a.mm_stride[j] = 0;
+  }
+  a.out_w = out_w;
+  a.out_b = out_b;
+  a.out_rows = out_rows;
+  a.n_ops = n_ops;
+  a.total_tiles = n_tasks * tiles_per_task;
+  a.tiles_per_task = tiles_per_task;
+  a.pts_per_task = pts_per_task;
+  a.wgs_per_task = 0;
+  a.xcd_remap = 0;
+  return NPF_OK;
+}
+
+}  // namespace npf

@@ -17,7 +17,7 @@
 // runs on ACROSS ops (slab S + 2 in flight while slab S multiplies, one counted s_waitcnt vmcnt + one barrier per slab).
 // The softmax of a score row is in registers: a lane holds F / 4 keys of its point, the four lanes of a point meet by two
 // wavefront shuffles (ds_bpermute), fp32 with max subtraction like torch.softmax.
-#include "npf_common.hpp"
+#include "x6_args.hpp"
 
 // Timing-only diagnostic builds (tools/fastbuild.sh x6_kernel OUT.so -DXP_NO_...): each removes one ingredient of the slab
 // loop, results are garbage, only the clock counts.  None is defined in the library build.
@@ -25,23 +25,6 @@
 //   XP_NO_STORE no global stores of the ops XP_NO_SPLIT the layer input is not split (bits reinterpreted)
 
 namespace npf {
-
-typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned xp_u32x4 __attribute__((ext_vector_type(4)));
-
-struct XpArgs {
-  npf_x6_op_t op[NPF_X6_MAX_OPS];
-  const char* mm_img[NPF_X6_MAX_OPS];  // the multiplies of the program in order (what the slab stream walks)
-  int64_t mm_stride[NPF_X6_MAX_OPS];
-  const float* out_w;
-  const float* out_b;
-  float* out_rows;
-  int32_t n_ops, n_mm;
-  int32_t total_tiles, tiles_per_task;
-  int32_t wgs_per_task;  // 0: tiles dealt flat (two or four per workgroup)
-  int32_t xcd_remap;     // the workgroups of a task on one XCD (grid a multiple of 8)
-  int32_t pts_per_task;  // valid points per task (row-major operands; PT32 operands are padded to whole tiles)
-};
 
 template <int KF>
 struct XpGeom {
@@ -56,17 +39,6 @@ struct XpGeom {
   static constexpr int NP = 3 * PPT / 4;          // pieces per wave and slab
   static constexpr int BiasB = 2 * KF * 4;
 };
-
-__device__ __forceinline__ void xp_dma16(const void* src, void* lds_wave_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
-}
-
-__device__ __forceinline__ unsigned xp_cvt_pk(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 
 // (see x6m_split in mlp_x6_kernel.hip for the edge-value semantics)
 __device__ __forceinline__ void xp_split(const f32x4& lo, const f32x4& hi, xp_u32x4& t0, xp_u32x4& t1, xp_u32x4& t2) {
@@ -88,18 +60,6 @@ __device__ __forceinline__ void xp_split(const f32x4& lo, const f32x4& hi, xp_u3
     t1[p] = m;
     t2[p] = xp_cvt_pk(la, lb);
   }
-}
-
-// sum / max over the four lanes (g = 0..3) that share a point
-__device__ __forceinline__ float xp_sum4(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-__device__ __forceinline__ float xp_max4(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
-  return v;
 }
 
 // NPG = 16-point groups per wave.  <256, 1> / <128, 1>: a wave owns half a tile, 216-256 registers, two workgroups per CU.
@@ -729,7 +689,8 @@ __global__ __launch_bounds__(512) void x6_wide512_kernel(const XpArgs a) {
 }
 
 // The three-term images of a PT32 tensor as per-task weights (npf_x6_task_images): one workgroup per (task, 32-point tile slot).
-template <int KF>
+// NT = terms written: 3 (the exact split), or 1 (the bf16 compute mode: the rounded value alone, npf_b16_task_images).
+template <int KF, int NT>
 __global__ __launch_bounds__(256) void x6_task_images_kernel(const float* __restrict__ src, int tiles_per_task, int pts,
                                                              unsigned short* __restrict__ row_img,
                                                              unsigned short* __restrict__ tr_img) {
@@ -775,9 +736,9 @@ __global__ __launch_bounds__(256) void x6_task_images_kernel(const float* __rest
 #pragma unroll
           for (int e = 0; e < 8; ++e) h[q][e] = 0;
       }
-      unsigned short* d = row_img + (size_t)task * 3 * img + (size_t)(ts * 32 + pt) * KF + ch * 8;
+      unsigned short* d = row_img + (size_t)task * NT * img + (size_t)(ts * 32 + pt) * KF + ch * 8;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *(uint4*)(d + q * img) = *(const uint4*)h[q];
+      for (int q = 0; q < NT; ++q) *(uint4*)(d + q * img) = *(const uint4*)h[q];
     }
   }
   // transposed image: row = feature, the tile's 32 columns = points, chunk gq = points 4 gq + i and 16 + 4 gq + i
@@ -791,9 +752,9 @@ __global__ __launch_bounds__(256) void x6_task_images_kernel(const float* __rest
         const float x = have ? tile_s[(f >> 2) * 33 + pt][f & 3] : 0.f;
         split3(x, h[0][e], h[1][e], h[2][e]);
       }
-      unsigned short* d = tr_img + (size_t)task * 3 * img + (size_t)f * KF + ts * 32 + gq * 8;
+      unsigned short* d = tr_img + (size_t)task * NT * img + (size_t)f * KF + ts * 32 + gq * 8;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *(uint4*)(d + q * img) = *(const uint4*)h[q];
+      for (int q = 0; q < NT; ++q) *(uint4*)(d + q * img) = *(const uint4*)h[q];
     }
   }
 }
@@ -803,56 +764,12 @@ __global__ __launch_bounds__(256) void x6_task_images_kernel(const float* __rest
 extern "C" int npf_x6_run_ex(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
                              int32_t n_tasks, int32_t tiles_per_task, int32_t pts_per_task, int32_t per_task, int32_t width,
                              int32_t variant, void* stream) {
-  if (!ops || n_ops <= 0 || n_ops > NPF_X6_MAX_OPS || n_tasks <= 0 || tiles_per_task <= 0) return NPF_EINVAL;
   if (width != 128 && width != 256 && width != 512) return NPF_EINVAL;
-  if (pts_per_task <= 0 || pts_per_task > tiles_per_task * 32 || pts_per_task <= (tiles_per_task - 1) * 32) return NPF_EINVAL;
   if (variant < 0 || variant > 3 || (variant >= 2 && width == 128) || (variant == 3 && width != 256)) return NPF_EINVAL;
-  if ((out_rows != nullptr) != (out_w != nullptr) || (out_b != nullptr && out_rows == nullptr)) return NPF_EINVAL;
-  if ((((uintptr_t)out_w) | ((uintptr_t)out_rows)) & 15) return NPF_EINVAL;
-  if (((uintptr_t)out_b) & 3) return NPF_EINVAL;
   npf::XpArgs a;
-  a.n_mm = 0;
-  bool have_cur = false;
-  for (int l = 0; l < n_ops; ++l) {
-    const npf_x6_op_t& o = ops[l];
-    if ((o.in_pt != nullptr) && (o.in_rows != nullptr)) return NPF_EINVAL;
-    if ((o.in_rows != nullptr) != (o.in_w != nullptr) || (o.in_b != nullptr && o.in_rows == nullptr)) return NPF_EINVAL;
-    if (o.in_rows != nullptr && (o.in_n <= 0 || o.in_n > width || (o.in_n & 15))) return NPF_EINVAL;
-    if (o.in_pt != nullptr || o.in_rows != nullptr) have_cur = true;
-    if (!have_cur) return NPF_EINVAL;  // (the first op must bring an input)
-    if (o.reserved[0] & ~(NPF_X6_IN_RM | NPF_X6_ADD_RM)) return NPF_EINVAL;
-    if (((o.reserved[0] & NPF_X6_IN_RM) && !o.in_pt) || ((o.reserved[0] & NPF_X6_ADD_RM) && !o.addend)) return NPF_EINVAL;
-    if ((((uintptr_t)o.in_pt) | ((uintptr_t)o.in_rows) | ((uintptr_t)o.in_w) | ((uintptr_t)o.in_b) | ((uintptr_t)o.pre_add) |
-         ((uintptr_t)o.mask) | ((uintptr_t)o.sbwd_p) | ((uintptr_t)o.store_in) | ((uintptr_t)o.w_img) | ((uintptr_t)o.addend) |
-         ((uintptr_t)o.store_out)) & 15)
-      return NPF_EINVAL;
-    if ((((uintptr_t)o.mask_bits) | ((uintptr_t)o.store_in_bits) | ((uintptr_t)o.store_bits)) & 7) return NPF_EINVAL;
-    // (a lane's ReLU bits are one 64-bit word: 16 blocks of 4 features; 512-wide programs are inference programs)
-    if (width > 256 && (o.mask_bits || o.store_in_bits || o.store_bits || o.sbwd_p || o.softmax_n)) return NPF_EINVAL;
-    if (((uintptr_t)o.bias) & 3) return NPF_EINVAL;
-    if ((o.w_task_stride & 15) || o.w_task_stride < 0 || o.bias_task_stride < 0) return NPF_EINVAL;
-    if ((o.w_task_stride != 0 || o.bias_task_stride != 0) && !per_task) return NPF_EINVAL;
-    if (o.softmax_n < 0 || o.softmax_n > width) return NPF_EINVAL;
-    if (o.w_img == nullptr && (o.bias || o.addend || o.store_out || o.store_bits || o.relu || o.softmax_n)) return NPF_EINVAL;
-    a.op[l] = o;
-    if (o.w_img != nullptr) {
-      a.mm_img[a.n_mm] = (const char*)o.w_img;
-      a.mm_stride[a.n_mm] = o.w_task_stride;
-      ++a.n_mm;
-    }
-  }
-  for (int l = n_ops; l < NPF_X6_MAX_OPS; ++l) a.op[l] = ops[0];
-  for (int j = a.n_mm; j < NPF_X6_MAX_OPS; ++j) {
-    a.mm_img[j] = a.n_mm ? a.mm_img[0] : nullptr;
-    a.mm_stride[j] = 0;
-  }
-  a.out_w = out_w;
-  a.out_b = out_b;
-  a.out_rows = out_rows;
-  a.n_ops = n_ops;
-  a.total_tiles = n_tasks * tiles_per_task;
-  a.tiles_per_task = tiles_per_task;
-  a.pts_per_task = pts_per_task;
+  const int rc = npf::xp_fill_args(ops, n_ops, out_w, out_b, out_rows, n_tasks, tiles_per_task, pts_per_task, per_task, width,
+                                   NPF_X6_IN_RM | NPF_X6_ADD_RM, 256, a);
+  if (rc != NPF_OK) return rc;
   // 256 features: 1 = a wave owns half a tile, four waves per workgroup, two workgroups per CU; 2 = a wave owns a whole tile (one
   // wave per SIMD); 3 = as 1 with eight waves per workgroup sharing one slab ring.  The library's choice is
   // NPF_X6_DEFAULT_VARIANT (measured on the config-2 train step: 3 -- 6.45 ms against 6.62 (1) and 7.85 (2))
@@ -892,19 +809,29 @@ extern "C" int npf_x6_run(const npf_x6_op_t* ops, int32_t n_ops, const float* ou
                        stream);
 }
 
-extern "C" int npf_x6_task_images(const float* src, int32_t n_tasks, int32_t pts, int32_t width, void* row_img, void* tr_img,
-                                  void* stream) {
+static int xp_task_images(const float* src, int32_t n_tasks, int32_t pts, int32_t width, void* row_img, void* tr_img, bool one_term,
+                          void* stream) {
   if (!src || n_tasks <= 0 || pts <= 0 || pts > width || (width != 128 && width != 256)) return NPF_EINVAL;
   if (!row_img && !tr_img) return NPF_EINVAL;
   if ((((uintptr_t)src) | ((uintptr_t)row_img) | ((uintptr_t)tr_img)) & 15) return NPF_EINVAL;
   const int tiles = (pts + 31) / 32;
-  const int n_wg = n_tasks * (width / 32);
-  if (width == 256)
-    hipLaunchKernelGGL(npf::x6_task_images_kernel<256>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, src, tiles, pts,
-                       (unsigned short*)row_img, (unsigned short*)tr_img);
-  else
-    hipLaunchKernelGGL(npf::x6_task_images_kernel<128>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, src, tiles, pts,
-                       (unsigned short*)row_img, (unsigned short*)tr_img);
+  const dim3 grid(n_tasks * (width / 32)), block(256);
+  unsigned short *ri = (unsigned short*)row_img, *ti = (unsigned short*)tr_img;
+  hipStream_t st = (hipStream_t)stream;
+  if (width == 256 && !one_term) hipLaunchKernelGGL((npf::x6_task_images_kernel<256, 3>), grid, block, 0, st, src, tiles, pts, ri, ti);
+  else if (width == 256) hipLaunchKernelGGL((npf::x6_task_images_kernel<256, 1>), grid, block, 0, st, src, tiles, pts, ri, ti);
+  else if (!one_term) hipLaunchKernelGGL((npf::x6_task_images_kernel<128, 3>), grid, block, 0, st, src, tiles, pts, ri, ti);
+  else hipLaunchKernelGGL((npf::x6_task_images_kernel<128, 1>), grid, block, 0, st, src, tiles, pts, ri, ti);
   NPF_CHECK_LAUNCH();
   return NPF_OK;
+}
+
+extern "C" int npf_x6_task_images(const float* src, int32_t n_tasks, int32_t pts, int32_t width, void* row_img, void* tr_img,
+                                  void* stream) {
+  return xp_task_images(src, n_tasks, pts, width, row_img, tr_img, false, stream);
+}
+
+extern "C" int npf_b16_task_images(const float* src, int32_t n_tasks, int32_t pts, int32_t width, void* row_img, void* tr_img,
+                                   void* stream) {
+  return xp_task_images(src, n_tasks, pts, width, row_img, tr_img, true, stream);
 }

@@ -134,8 +134,13 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
         T = X_trgt.shape[1]
         if T == 0:
             raise ValueError("no target points")
+        from . import chain as _chain
+
         fused_t = self._fused_target_side(C, T)
-        if self._fused_context_side(C):
+        fused_c = self._fused_context_side(C)
+        if fused_c and self._attentive and not fused_t and _chain.COMPUTE_DTYPE == "bf16":
+            fused_c = False  # (the bf16 attention chain streams the bf16 images of keys / values its producer chains store)
+        if fused_c:
             # x-encoder + XY-encoder of the context points as one x6 program (x6.py); the pooling stays the subclass's
             from . import x6
 

@@ -29,13 +29,20 @@ WIDTH = 256
 # and all 512 features (one wave per SIMD), 0 / 2 = the contraction split over pairs of waves (plain layers only, two waves per
 # SIMD, the default).  NPF_X6_VARIANT is a development / A-B switch
 VARIANT = int(os.environ.get("NPF_X6_VARIANT", "0"))
+# the bf16 compute mode on the fused sides (b16 programs); NPF_NO_B16_FUSED=1: the bf16 chain launches of round 2 instead
+B16_ENABLED = os.environ.get("NPF_NO_B16_FUSED", "0") != "1"
+B16_VARIANT = int(os.environ.get("NPF_B16_VARIANT", "0"))  # npf_b16_run ``variant`` (A-B switch)
 
 
 class Program:
     """A list of ``npf_x6_op_t`` + geometry; ``launch()`` calls ``npf_x6_run``."""
 
-    def __init__(self, n_tasks: int, tiles: int, per_task: bool, width: int = WIDTH, pts: Optional[int] = None):
+    def __init__(self, n_tasks: int, tiles: int, per_task: bool, width: int = WIDTH, pts: Optional[int] = None,
+                 bf16: bool = False):
         self.n_tasks, self.tiles, self.per_task, self.width = n_tasks, tiles, per_task, width
+        # bf16: a b16 program (``npf_b16_run``, csrc/b16_kernel.hip) -- the bf16 compute mode: one-term images, store_in /
+        # store_out / sbwd_p are PT16 tensors unless the op says ``store_in_f32`` / ``store_out_f32``
+        self.bf16 = bf16
         self.pts = tiles * 32 if pts is None else pts  # valid points per task (row-major operands are indexed with it)
         self.ops: List[dict] = []
         self.tail = None  # (W [4, F], b [4] or None, rows [points, 4])
@@ -53,10 +60,12 @@ class Program:
             raise RuntimeError(f"x6 program operand {what} must be a contiguous device tensor")
         return t.data_ptr()
 
-    def _pt_ok(self, t, what):
-        want = (self.n_tasks, self.tiles, self.width // 4, 32, 4)
-        if t is not None and (tuple(t.shape) != want or t.dtype != torch.float32):
-            raise ValueError(f"x6 program operand {what}: PT32 tensor {tuple(t.shape)} {t.dtype}, expected {want} float32")
+    def _pt_ok(self, t, what, p16=False):
+        want = (self.n_tasks, self.tiles, self.width // 8, 32, 8) if p16 else (self.n_tasks, self.tiles, self.width // 4, 32, 4)
+        dt = torch.bfloat16 if p16 else torch.float32
+        if t is not None and (tuple(t.shape) != want or t.dtype != dt):
+            raise ValueError(f"x6 program operand {what}: {'PT16' if p16 else 'PT32'} tensor {tuple(t.shape)} {t.dtype}, "
+                             f"expected {want} {dt}")
 
     def launch(self) -> None:
         if len(self.ops) > L.NPF_X6_MAX_OPS:
@@ -72,11 +81,18 @@ class Program:
                 if t is not None and o.get(k + "_rm"):  # a row-major [n_tasks, pts, F] operand (in_pt / addend only)
                     if k not in ("in_pt", "addend") or tuple(t.shape) != (self.n_tasks, self.pts, F) or t.dtype != torch.float32:
                         raise ValueError(f"x6 program operand {k}: row-major tensor {tuple(t.shape)} {t.dtype}")
+                    if self.bf16:
+                        raise ValueError("b16 programs take no row-major operands")
                     flags |= L.X6_IN_RM if k == "in_pt" else L.X6_ADD_RM
                 else:
-                    self._pt_ok(t, k)
+                    p16 = self.bf16 and (k == "sbwd_p" or (k in ("store_in", "store_out") and not o.get(k + "_f32")))
+                    if self.bf16 and k in ("store_in", "store_out") and o.get(k + "_f32") and t is not None:
+                        flags |= L.X6_STORE_IN_F32 if k == "store_in" else L.X6_STORE_OUT_F32
+                    if self.bf16 and k == "mask" and t is not None:
+                        raise ValueError("b16 programs take ReLU masks as bits")
+                    self._pt_ok(t, k, p16)
                 setattr(arr[j], k, self._ptr(t, k))
-                nbytes += pts * F * 4 if t is not None else 0
+                nbytes += pts * F * (t.element_size() if t is not None else 0)
             arr[j].reserved[0] = flags
             for k in ("mask_bits", "store_in_bits", "store_bits"):
                 t = o.get(k)
@@ -98,11 +114,12 @@ class Program:
             img = o.get("img")
             if img is not None:
                 per_task = bool(o.get("img_per_task", False))
-                want = (self.n_tasks, 3, F, F) if per_task else (3, F, F)
+                terms = (1,) if self.bf16 else (3,)
+                want = ((self.n_tasks,) if per_task else ()) + (() if self.bf16 else (3,)) + (F, F)
                 if tuple(img.shape) != want or img.dtype != torch.bfloat16 or not img.is_contiguous():
                     raise ValueError(f"x6 program weight image {tuple(img.shape)} {img.dtype}, expected {want} bfloat16")
                 arr[j].w_img = img.data_ptr()
-                arr[j].w_task_stride = 3 * F * F * 2 if per_task else 0
+                arr[j].w_task_stride = terms[0] * F * F * 2 if per_task else 0
                 bias = o.get("bias")
                 if bias is not None:
                     bpt = bool(o.get("bias_per_task", False))
@@ -114,7 +131,7 @@ class Program:
                 arr[j].softmax_n = int(o.get("softmax_n", 0))
                 arr[j].softmax_scale = float(o.get("softmax_scale", 1.0))
                 flops += 2 * o.get("true_k", F) * o.get("true_n", F) * pts
-                nbytes += 3 * 2 * F * F * (self.n_tasks if per_task else 1)
+                nbytes += terms[0] * 2 * F * F * (self.n_tasks if per_task else 1)
             elif any(o.get(k) is not None for k in ("bias", "addend", "store_out", "store_bits")) or o.get("relu") or o.get("softmax_n"):
                 raise ValueError("x6 program: an op without a multiply has no output side")
             arr[j].sbwd_scale = float(o.get("sbwd_scale", 1.0))
@@ -125,40 +142,63 @@ class Program:
         if CH.PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        L.check(L.load().npf_x6_run_ex(arr, len(self.ops), L.ptr(tail[0]) if tail else None,
-                                       L.ptr(tail[1]) if (tail and tail[1] is not None) else None,
-                                       L.ptr(tail[2]) if tail else None, self.n_tasks, self.tiles, self.pts, int(self.per_task), F,
-                                       VARIANT if F in (256, 512) else 0, L.stream_ptr()), "npf_x6_run_ex")
+        tw, tb, tr = (L.ptr(tail[0]) if tail else None, L.ptr(tail[1]) if (tail and tail[1] is not None) else None,
+                      L.ptr(tail[2]) if tail else None)
+        if self.bf16:
+            if self.pts != self.tiles * 32:
+                raise ValueError("b16 programs run on whole tiles")
+            L.check(L.load().npf_b16_run(arr, len(self.ops), tw, tb, tr, self.n_tasks, self.tiles, int(self.per_task), F,
+                                         B16_VARIANT, L.stream_ptr()), "npf_b16_run")
+        else:
+            L.check(L.load().npf_x6_run_ex(arr, len(self.ops), tw, tb, tr, self.n_tasks, self.tiles, self.pts, int(self.per_task), F,
+                                           VARIANT if F in (256, 512) else 0, L.stream_ptr()), "npf_x6_run_ex")
         if CH.PROFILE is not None:
             ev1.record()
-            CH.PROFILE.append(("x6_program_kernel", flops, ev0, ev1, nbytes, self.tag))
+            CH.PROFILE.append(("b16_program_kernel" if self.bf16 else "x6_program_kernel", flops, ev0, ev1, nbytes, self.tag))
+        if CH.TRACE is not None:
+            CH.TRACE.append(("prog", self))
 
 
-def task_images(pt: torch.Tensor, pts: int, row: bool = True, tr: bool = True, width: int = WIDTH):
+def task_images(pt: torch.Tensor, pts: int, row: bool = True, tr: bool = True, width: int = WIDTH, bf16: bool = False):
     """Three-term images of a PT32 tensor [n_tasks, tiles, F/4, 32, 4] taken as per-task weights (``npf_x6_task_images``):
-    (row image W[n = point][k = feature], transposed image W[n = feature][k = point]), each [n_tasks, 3, F, F] bf16 or None."""
+    (row image W[n = point][k = feature], transposed image W[n = feature][k = point]), each [n_tasks, 3, F, F] bf16 or None.
+    ``bf16``: the rounded value alone, [n_tasks, F, F] (``npf_b16_task_images``, the bf16 compute mode)."""
     n_tasks = pt.shape[0]
     if tuple(pt.shape) != (n_tasks, CH.tiles_of(pts), width // 4, 32, 4) or pts > width:
         raise ValueError(f"task_images: PT32 tensor {tuple(pt.shape)} for {pts} points x {width} features")
-    mk = lambda: torch.empty((n_tasks, 3, width, width), dtype=torch.bfloat16, device=pt.device)  # noqa: E731
+    shape = (n_tasks, width, width) if bf16 else (n_tasks, 3, width, width)
+    mk = lambda: torch.empty(shape, dtype=torch.bfloat16, device=pt.device)  # noqa: E731
     ri, ti = (mk() if row else None), (mk() if tr else None)
     if CH.PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    L.check(L.load().npf_x6_task_images(L.ptr(pt.detach().contiguous()), n_tasks, pts, width,
-                                        ri.data_ptr() if row else None, ti.data_ptr() if tr else None, L.stream_ptr()),
-            "npf_x6_task_images")
+    fn = L.load().npf_b16_task_images if bf16 else L.load().npf_x6_task_images
+    L.check(fn(L.ptr(pt.detach().contiguous()), n_tasks, pts, width, ri.data_ptr() if row else None,
+               ti.data_ptr() if tr else None, L.stream_ptr()), "npf_x6_task_images")
     if CH.PROFILE is not None:
         ev1.record()
         CH.PROFILE.append(("x6_task_images_kernel", 0, ev0, ev1,
-                           pt.numel() * 4 + (int(row) + int(tr)) * n_tasks * 3 * width * width * 2))
+                           pt.numel() * 4 + (int(row) + int(tr)) * n_tasks * (1 if bf16 else 3) * width * width * 2))
     return ri, ti
 
 
-def _weight_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int], width: int = WIDTH) -> List[List[torch.Tensor]]:
+def _weight_images(Ws: Sequence[torch.Tensor], kinds: Sequence[int], width: int = WIDTH, bf16: bool = False) -> List[List[torch.Tensor]]:
+    """Per kind (1: of W, 2: of W^T) and weight matrix [F, F] its image: [3, F, F] (three exact bf16 terms), or -- ``bf16`` -- the
+    one-term image [F, F] = bf16(W) (both k-permuted, ``npf_prepare_weights``)."""
+    if bf16:
+        n = len(Ws)
+        buf = torch.empty((len(kinds), n, width, width), dtype=torch.bfloat16, device=Ws[0].device)
+        CH.prepare_weights([(Ws[i].detach(), kind) for kind in kinds for i in range(n)],
+                           dsts=[buf[k, i] for k in range(len(kinds)) for i in range(n)])
+        return [[buf[k, i] for i in range(n)] for k in range(len(kinds))]
     from .mlp_x6 import _three_term_images
 
     return _three_term_images(Ws, kinds, width)
+
+
+def _r16(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A tensor as the bf16 mode's multiplies see it: rounded to bfloat16 (nearest even), kept as fp32."""
+    return None if t is None else t.to(torch.bfloat16).to(torch.float32)
 
 
 def _bits(n_tasks, tiles, dev):
@@ -266,57 +306,66 @@ class _TargetSideFn(torch.autograd.Function):
         if n_mrz:
             mid_b[n_x] = zb
         train = any(ctx.needs_input_grad)
-        imgs = _weight_images(mid_W, (1, 2) if train else (1,), F)
+        # bf16 compute mode (config 3): a b16 program -- one-term images, bf16-rounded rows / small matrices, and the tensors only
+        # the backward pass reads as PT16 (``pb``); what an fp32 consumer reads (the merge's addend, the outputs) stays PT32
+        bf16 = CH.COMPUTE_DTYPE == "bf16"
+        imgs = _weight_images(mid_W, (1, 2) if train else (1,), F, bf16)
         fw = imgs[0]
-        K_row, K_tr = task_images(K_pt, C, row=True, tr=train, width=F)
-        V_row, V_tr = task_images(V_pt, C, row=train, tr=True, width=F)
+        K_row, K_tr = task_images(K_pt, C, row=True, tr=train, width=F, bf16=bf16)
+        V_row, V_tr = task_images(V_pt, C, row=train, tr=True, width=F, bf16=bf16)
         X4 = _pad_rows4(X.detach())
         W1p = _first_layer_matrix(W1, F)
+        if bf16:
+            X4, W1p = _r16(X4), _r16(W1p)
         pt = lambda: CH.pt_empty(B, T, F, dev)  # noqa: E731
-        prog = Program(B, tiles, per_task=True, width=F)
+        pb = (lambda: CH.pt16_empty(B, T, F, dev)) if bf16 else pt  # noqa: E731
+        prog = Program(B, tiles, per_task=True, width=F, bf16=bf16)
         saved_acts, saved_bits = [], []
         # x-encoder: first layer in the prologue, then its 256 -> 256 layers (ReLU on all but the last, mlp.py:95-109)
-        h1 = pt() if train else None
+        h1 = pb() if train else None
         bits_h1 = _bits(B, tiles, dev) if train else None
         Xt_enc = pt()
-        cur_in = h1
         for i in range(n_x):
             last = i == n_x - 1
-            o = dict(img=fw[i], bias=mid_b[i].detach() if mid_b[i] is not None else None, relu=not last)
+            o = dict(img=fw[i], w_ref=("shared", mid_W[i]), bias=mid_b[i].detach() if mid_b[i] is not None else None, relu=not last)
             if i == 0:
                 o.update(in_rows=X4, in_w=W1p, in_b=b1.detach() if b1 is not None else None, in_relu=True, store_in=h1,
                          store_in_bits=bits_h1)
             if last:
-                o["store_out"] = Xt_enc
+                o["store_out"], o["store_out_f32"] = Xt_enc, True
             elif train:
-                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                o["store_out"], o["store_bits"] = pb(), _bits(B, tiles, dev)
                 saved_acts.append(o["store_out"])
                 saved_bits.append(o["store_bits"])
             prog.op(**o)
         # attention (attention.py:129-164, 204-220): scores = K q, softmax(scale .), attn . V
-        P = pt() if train else None
-        prog.op(img=K_row, img_per_task=True, softmax_n=C, softmax_scale=scale, store_out=P, true_n=C)
-        R_trgt = pt() if train else None
-        prog.op(img=V_tr, img_per_task=True, store_out=R_trgt, true_k=C)
+        P = pb() if train else None
+        prog.op(img=K_row, w_ref=("task_row", K_pt, C), img_per_task=True, softmax_n=C, softmax_scale=scale, store_out=P, true_n=C)
+        R_trgt = pb() if train else None
+        prog.op(img=V_tr, w_ref=("task_tr", V_pt, C), img_per_task=True, store_out=R_trgt, true_k=C)
         # [latent merge relu(W_R R_trgt + zb[task])], decoder: resizer, merge relu(x1 + .) (encoders.py:178-179), flat MLP
         for i in range(n_mrz + n_res + n_flat):
             j = n_x + i
-            o = dict(img=fw[j], bias=mid_b[j].detach().contiguous() if mid_b[j] is not None else None, relu=True,
-                     bias_per_task=bool(n_mrz and i == 0))
+            o = dict(img=fw[j], w_ref=("shared", mid_W[j]), bias=mid_b[j].detach().contiguous() if mid_b[j] is not None else None,
+                     relu=True, bias_per_task=bool(n_mrz and i == 0))
             if i == n_mrz + n_res - 1:
                 o["addend"] = Xt_enc
             if train:
-                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                o["store_out"], o["store_bits"] = pb(), _bits(B, tiles, dev)
                 saved_acts.append(o["store_out"])
                 saved_bits.append(o["store_bits"])
             prog.op(**o)
         rows = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
         Wo, bo = _pad_out(W_out, b_out)
+        if bf16:
+            Wo = _r16(Wo)
         prog.tail = (Wo, bo, rows)
         prog.tag = "target side forward (x-encoder, attention, decoder, output layer)"
         prog.launch()
         ctx.geom = (B, T, tiles, dx, C, float(scale), n_out, F)
-        ctx.spec = spec
+        ctx.spec, ctx.bf16 = spec, bf16
+        # (a traced run -- tests/teacher.py -- names the matrices behind the images of the backward launch too)
+        ctx.trace_ref = ([W.detach() for W in mid_W], K_pt, V_pt) if CH.TRACE is not None else None
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
         if train:
@@ -340,33 +389,42 @@ class _TargetSideFn(torch.autograd.Function):
         rest = sv[6 + ctx.n_acts + ctx.n_bits:]
         bw, (V_row, K_tr, Wo) = rest[:n_mid], rest[n_mid:]
         dev = g.device
+        bf16 = ctx.bf16
         g4 = g.contiguous() if n_out == 4 else torch.nn.functional.pad(g, (0, 4 - n_out)).contiguous()
+        if bf16:
+            g4 = _r16(g4)  # (the output layer's dZ as its dgrad and weight gradient see it; Wo was saved rounded)
         pt = lambda: CH.pt_empty(B, T, F, dev)  # noqa: E731
+        pb = (lambda: CH.pt16_empty(B, T, F, dev)) if bf16 else pt  # noqa: E731
         # the saved outputs by layer: x-encoder hidden layers (n_x - 1 of them), then resizer + flat (all ReLU layers)
         x_acts, x_bits = acts[:n_x - 1], bits[:n_x - 1]
         d_acts, d_bits = acts[n_x - 1:], bits[n_x - 1:]
-        prog = Program(B, tiles, per_task=True, width=F)
+        prog = Program(B, tiles, per_task=True, width=F, bf16=bf16)
+        tr = ctx.trace_ref
+        wref = lambda j: ("shared", tr[0][j].t()) if tr is not None else None  # noqa: E731
         dz = [None] * n_mid  # dZ of every 256 -> 256 layer (index as in the forward: x-encoder, resizer, flat)
-        # decoder layers (and the latent merge), last to first
+        # decoder layers (and the latent merge), last to first.  (bf16 mode: a dZ is a PT16 tensor -- the rounded values its
+        # weight gradient multiplies and its bias gradient sums -- except the merge layer's, which is also the fp32 gradient of x1)
         for i in range(n_dec - 1, -1, -1):
             j = n_x + i
-            dz[j] = pt()
-            o = dict(mask_bits=d_bits[i], store_in=dz[j], img=bw[j])
+            is_merge = i == n_mrz + n_res - 1
+            dz[j] = pt() if is_merge else pb()
+            o = dict(mask_bits=d_bits[i], store_in=dz[j], store_in_f32=is_merge, img=bw[j], w_ref=wref(j))
             if i == n_dec - 1:
                 o.update(in_rows=g4, in_w=Wo)  # the dgrad of the output layer in the prologue
             prog.op(**o)
         # attention backward: dO -> dP = V dO ; dS = softmax'(dP) ; dq = K^T dS, + the merge's gradient wrt x1 (fan-in)
-        dO, dS = pt(), pt()
-        prog.op(store_in=dO, img=V_row, img_per_task=True, true_n=C)
-        prog.op(sbwd_p=P, sbwd_scale=scale, store_in=dS, img=K_tr, img_per_task=True, addend=dz[n_x + n_mrz + n_res - 1], true_k=C)
+        dO, dS = pb(), pb()
+        prog.op(store_in=dO, img=V_row, w_ref=("task_row", tr[2], C) if tr is not None else None, img_per_task=True, true_n=C)
+        prog.op(sbwd_p=P, sbwd_scale=scale, store_in=dS, img=K_tr, w_ref=("task_tr", tr[1], C) if tr is not None else None,
+                img_per_task=True, addend=dz[n_x + n_mrz + n_res - 1], true_k=C)
         # x-encoder, last to first; the first layer's dZ behind its ReLU mask closes the program
         for i in range(n_x - 1, -1, -1):
-            dz[i] = pt()
-            o = dict(store_in=dz[i], img=bw[i])
+            dz[i] = pb()
+            o = dict(store_in=dz[i], img=bw[i], w_ref=wref(i))
             if i < n_x - 1:
                 o["mask_bits"] = x_bits[i]
             prog.op(**o)
-        dz1 = pt()
+        dz1 = pb()
         prog.op(mask_bits=bits_h1, store_in=dz1)
         prog.tag = "target side dgrad (decoder, attention backward, x-encoder)"
         prog.launch()
@@ -398,6 +456,8 @@ class _TargetSideFn(torch.autograd.Function):
         if dK is not None:
             jobs.append(dict(dZ=dS, A=Xt_enc, N=C, K=F, dW=dK, per_task=True, ldz=F))
         CH.run_wgrad(jobs, B, T, dev, tag="target side weight / key / value gradients")
+        if CH.TRACE is not None:
+            CH.TRACE.append(("wgrad", jobs, B, T, bf16))
         grads[0] = dW1p[:, :dx].contiguous() if dx != 4 else dW1p
         # the per-task bias of the latent merge: the sum of its dZ over the task's points (padding points carry zeros: their
         # incoming gradient is zero)
@@ -411,6 +471,11 @@ def _width_of(model) -> int:
     return F if (F in (128, 256) and getattr(model, "x_transf_dim", F) == F) else 0
 
 
+def _mode_ok() -> bool:
+    """The fused sides exist for the fp32 mode (x6 programs) and the bf16 compute mode (b16 programs)."""
+    return ENABLED and (CH.COMPUTE_DTYPE == "fp32" or (CH.COMPUTE_DTYPE == "bf16" and B16_ENABLED))
+
+
 def _square(lins, width=WIDTH) -> bool:
     return all(l.in_features == width and l.out_features == width for l in lins)
 
@@ -420,7 +485,7 @@ def target_side_usable(model, C: int, T: int, latent_merge: bool = False) -> boo
     wide layer 256 -> 256, no residual / dropout; ``latent_merge``: with AttnLNP's merge_r_z between attention and decoder."""
     from .architectures import MLP, DotAttender
 
-    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32"):
+    if not _mode_ok() or (latent_merge and CH.COMPUTE_DTYPE != "fp32"):
         return False
     WIDTH = _width_of(model)
     if not WIDTH:
@@ -498,56 +563,63 @@ class _ContextSideFn(torch.autograd.Function):
         h = Wr1.shape[0]
         F = Wr2.shape[0]  # the width of every other layer: 128 or 256
         train = any(ctx.needs_input_grad)
+        bf16 = CH.COMPUTE_DTYPE == "bf16"  # (see _TargetSideFn)
         Wr2p = torch.zeros((F, F), dtype=torch.float32, device=dev)  # (the h -> 256 layer as a 256-input layer:
         Wr2p[:, :h] = Wr2.detach()                                           #  the input's other registers are zero)
-        imgs = _weight_images([*x_W, Wr2p, *f_W], (1, 2) if train else (1,), F)
+        imgs = _weight_images([*x_W, Wr2p, *f_W], (1, 2) if train else (1,), F, bf16)
         fw = imgs[0]
         X4, Y4 = _pad_rows4(X.detach()), _pad_rows4(Y.detach())
+        W1p, Wr1p = _first_layer_matrix(W1, F), _first_layer_matrix(Wr1, h)
+        if bf16:
+            X4, Y4, W1p, Wr1p = _r16(X4), _r16(Y4), _r16(W1p), _r16(Wr1p)
         pt = lambda: CH.pt_empty(B, Cn, F, dev)  # noqa: E731
-        prog = Program(B, tiles, per_task=False, width=F)
+        pb = (lambda: CH.pt16_empty(B, Cn, F, dev)) if bf16 else pt  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F, bf16=bf16)
         acts, bits = [], []
-        h1 = pt() if train else None
+        h1 = pb() if train else None
         bits_h1 = _bits(B, tiles, dev) if train else None
         Xc_enc = pt()
         for i in range(n_x):
             last = i == n_x - 1
-            o = dict(img=fw[i], bias=x_b[i].detach() if x_b[i] is not None else None, relu=not last)
+            o = dict(img=fw[i], w_ref=("shared", x_W[i]), bias=x_b[i].detach() if x_b[i] is not None else None, relu=not last)
             if i == 0:
-                o.update(in_rows=X4, in_w=_first_layer_matrix(W1, F), in_b=b1.detach() if b1 is not None else None,
+                o.update(in_rows=X4, in_w=W1p, in_b=b1.detach() if b1 is not None else None,
                          in_relu=True, store_in=h1, store_in_bits=bits_h1)
             if last:
-                o["store_out"] = Xc_enc
+                o["store_out"], o["store_out_f32"] = Xc_enc, True
             elif train:
-                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                o["store_out"], o["store_bits"] = pb(), _bits(B, tiles, dev)
                 acts.append(o["store_out"])
                 bits.append(o["store_bits"])
             prog.op(**o)
         # resizer(y): first layer in the prologue (h features), second layer + x1 + ReLU = the merge
-        hy = pt() if train else None
+        hy = pb() if train else None
         bits_hy = _bits(B, tiles, dev) if train else None
-        o = dict(in_rows=Y4, in_w=_first_layer_matrix(Wr1, h), in_b=br1.detach() if br1 is not None else None, in_relu=True,
-                 store_in=hy, store_in_bits=bits_hy, img=fw[n_x], bias=br2.detach() if br2 is not None else None, relu=True,
-                 addend=Xc_enc, true_k=h)
+        o = dict(in_rows=Y4, in_w=Wr1p, in_b=br1.detach() if br1 is not None else None, in_relu=True,
+                 store_in=hy, store_in_bits=bits_hy, img=fw[n_x], w_ref=("shared", Wr2p),
+                 bias=br2.detach() if br2 is not None else None, relu=True, addend=Xc_enc, true_k=h)
         if train:
-            o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+            o["store_out"], o["store_bits"] = pb(), _bits(B, tiles, dev)
             acts.append(o["store_out"])
             bits.append(o["store_bits"])
         prog.op(**o)
         R = pt()
         for i in range(n_flat):
             last = i == n_flat - 1
-            o = dict(img=fw[n_x + 1 + i], bias=f_b[i].detach() if f_b[i] is not None else None, relu=not last)
+            o = dict(img=fw[n_x + 1 + i], w_ref=("shared", f_W[i]), bias=f_b[i].detach() if f_b[i] is not None else None,
+                     relu=not last)
             if last:
-                o["store_out"] = R
+                o["store_out"], o["store_out_f32"] = R, True
             elif train:
-                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                o["store_out"], o["store_bits"] = pb(), _bits(B, tiles, dev)
                 acts.append(o["store_out"])
                 bits.append(o["store_bits"])
             prog.op(**o)
         prog.tag = "context side forward (x-encoder, XY-encoder)"
         prog.launch()
         ctx.geom = (B, Cn, tiles, dx, dy, h, F)
-        ctx.spec = spec
+        ctx.spec, ctx.bf16 = spec, bf16
+        ctx.trace_ref = [W.detach() for W in (*x_W, Wr2p, *f_W)] if CH.TRACE is not None else None
         ctx.has_b = [b is not None for b in bs]
         ctx.set_materialize_grads(False)
         if train:
@@ -567,11 +639,14 @@ class _ContextSideFn(torch.autograd.Function):
         acts, bits = sv[6:6 + ctx.n_acts], sv[6 + ctx.n_acts:6 + 2 * ctx.n_acts]
         bw = sv[6 + 2 * ctx.n_acts:]
         dev = X4.device
+        bf16 = ctx.bf16
         pt = lambda: CH.pt_empty(B, Cn, F, dev)  # noqa: E731
+        pb = (lambda: CH.pt16_empty(B, Cn, F, dev)) if bf16 else pt  # noqa: E731
         x_acts, x_bits = acts[:n_x - 1], bits[:n_x - 1]
         m_act, m_bits = acts[n_x - 1], bits[n_x - 1]          # the merge's output
         f_acts, f_bits = acts[n_x:], bits[n_x:]                 # flat hidden outputs (n_flat - 1 of them)
-        prog = Program(B, tiles, per_task=False, width=F)
+        prog = Program(B, tiles, per_task=False, width=F, bf16=bf16)
+        wref = lambda j: ("shared", ctx.trace_ref[j].t()) if ctx.trace_ref is not None else None  # noqa: E731
         jobs, grads = [], [None] * n_par
 
         def wjob(pos, dZ, A, N, K, **kw):
@@ -587,18 +662,22 @@ class _ContextSideFn(torch.autograd.Function):
             # flat MLP, last to first; the output layer's dZ is the incoming gradient itself
             f_in = [m_act, *f_acts]
             for i in range(n_flat - 1, -1, -1):
-                o = dict(img=bw[n_x + 1 + i])
+                o = dict(img=bw[n_x + 1 + i], w_ref=wref(n_x + 1 + i))
                 if i == n_flat - 1:
                     o["in_pt"] = gR
                     dz = gR
+                    if bf16:  # (the rounded incoming gradient: what the weight gradient multiplies and the bias gradient sums)
+                        dz = pb()
+                        o["store_in"] = dz
                 else:
-                    dz = pt()
+                    dz = pb()
                     o.update(mask_bits=f_bits[i], store_in=dz)
                 prog.op(**o)
                 wjob(1 + n_x + 2 + i, dz, f_in[i], F, F)
-            # the merge relu(x1 + W_r2 hy + b): its dZ is also the gradient wrt x1; then back through the h-wide first layer
-            dz_m, dz_hy = pt(), pt()
-            prog.op(mask_bits=m_bits, store_in=dz_m, img=bw[n_x])
+            # the merge relu(x1 + W_r2 hy + b): its dZ is also the gradient wrt x1 (fp32 in either mode); then back through the
+            # h-wide first layer
+            dz_m, dz_hy = pt(), pb()
+            prog.op(mask_bits=m_bits, store_in=dz_m, store_in_f32=True, img=bw[n_x], w_ref=wref(n_x))
             prog.op(mask_bits=bits_hy, store_in=dz_hy)
             wjob(1 + n_x + 1, dz_m, hy, F, h, lda=F)
             dWr1 = wjob(1 + n_x, dz_hy, FN._pack(Y4), h, 4, ldz=F)
@@ -607,20 +686,22 @@ class _ContextSideFn(torch.autograd.Function):
             first = dict(in_pt=gK.contiguous(), pre_add=dz_m) if gK is not None else dict(in_pt=dz_m)
             x_in = [h1, *x_acts]
             for i in range(n_x - 1, -1, -1):
-                dz = pt()
-                o = dict(store_in=dz, img=bw[i])
+                dz = pb()
+                o = dict(store_in=dz, img=bw[i], w_ref=wref(i))
                 if i == n_x - 1:
                     o.update(first)
                 else:
                     o["mask_bits"] = x_bits[i]
                 prog.op(**o)
                 wjob(1 + i, dz, x_in[i], F, F)
-            dz1 = pt()
+            dz1 = pb()
             prog.op(mask_bits=bits_h1, store_in=dz1)
             dW1p = wjob(0, dz1, FN._pack(X4), F, 4)
         prog.tag = "context side dgrad (XY-encoder, x-encoder)"
         prog.launch()
         CH.run_wgrad(jobs, B, Cn, dev, tag="context side weight gradients")
+        if CH.TRACE is not None:
+            CH.TRACE.append(("wgrad", jobs, B, Cn, bf16))
         if gR is not None and dy != 4:
             grads[2 * (1 + n_x)] = dWr1[:, :dy].contiguous()
         if (gK is not None or dz_m is not None) and dx != 4:
@@ -633,7 +714,7 @@ def context_side_usable(model, C: int) -> bool:
     with 256-wide layers, no residual / dropout, a two-layer resizer (dy -> h -> 256, h a multiple of 16), whole tiles."""
     from .architectures import MLP, MergeFlatInputs
 
-    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or C <= 0:
+    if not _mode_ok() or C <= 0:
         return False
     WIDTH = _width_of(model)
     if not WIDTH:

@@ -381,6 +381,136 @@ def walk_backward(rec, rep: Report, tag: str = "") -> None:
                        TOL_STEP)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# x6 / b16 programs (npf_gwwaveform_amd/x6.py ``Program``: one launch = a list of ops on the register-resident activation)
+# ---------------------------------------------------------------------------------------------------------------------------
+def unpack_xbits(b: torch.Tensor, F: int) -> torch.Tensor:
+    """ReLU bits of the program kernels [n, tiles, 2 halves, 64 lanes] int64 -> bool [n, tiles * 32, F]: bit 4 b + e of lane
+    (p = lane % 16, g = lane // 16) = feature 16 b + 4 g + e of point 16 half + p (include/npf_hip.h)."""
+    n, tiles = b.shape[:2]
+    w = b.detach().cpu().view(n, tiles, 2, 4, 16)           # [.., half, g, p]
+    out = torch.zeros(n, tiles, 2, 16, F, dtype=torch.bool)  # [.., half, p, feature]
+    for blk in range(F // 16):
+        for e in range(4):
+            bit = ((w >> (4 * blk + e)) & 1).bool()          # [n, tiles, half, g, p]
+            for g in range(4):
+                out[..., 16 * blk + 4 * g + e] = bit[:, :, :, g, :]
+    return out.reshape(n, tiles * 32, F)
+
+
+def _op_weights(o, n: int, F: int) -> torch.Tensor:
+    """The fp32 matrix W [n or 1, F out, F in] an op multiplies by (``w_ref`` of the op: what its image was made from)."""
+    kind = o["w_ref"][0]
+    if kind == "shared":
+        W = o["w_ref"][1].detach().cpu().double()
+        Wp = torch.zeros(1, F, F, dtype=torch.float64)
+        Wp[0, :W.shape[0], :W.shape[1]] = W
+        return Wp
+    _, src, C = o["w_ref"]
+    M = unpack32(src, C, F)                                   # [n, C points, F features]
+    Wp = torch.zeros(n, F, F, dtype=torch.float64)
+    if kind == "task_row":                                    # W[point][feature]
+        Wp[:, :C, :] = M
+    else:                                                     # "task_tr": W[feature][point]
+        Wp[:, :, :C] = M.transpose(1, 2)
+    return Wp
+
+
+def walk_program(prog, rep: Report, tag: str = "") -> None:
+    """One program launch, op by op (include/npf_hip.h, npf_x6_op_t): every stored tensor against the op applied to the previous
+    STORED tensor.  b16 programs round the input of every multiply and the PT16 stores; x6 programs are fp32 throughout."""
+    n, pts, F = prog.n_tasks, prog.tiles * 32, prog.width
+    R = r16 if prog.bf16 else (lambda x: x)
+    cur = None
+    for l, o in enumerate(prog.ops):
+        name = f"{tag}op {l}"
+        if o.get("in_pt") is not None:
+            cur = unpack32(o["in_pt"], pts, F)
+        if o.get("in_rows") is not None:
+            rows, w = o["in_rows"].detach().cpu().double(), o["in_w"].detach().cpu().double()
+            v = rows @ w
+            if o.get("in_b") is not None:
+                v = v + o["in_b"].detach().cpu().double()
+            if o.get("in_relu"):
+                v = v.clamp_min(0.0)
+            cur = torch.zeros(n, pts, F, dtype=torch.float64)
+            cur[..., :v.shape[-1]] = v
+        if o.get("pre_add") is not None:
+            cur = cur + unpack32(o["pre_add"], pts, F)
+        if o.get("mask_bits") is not None:
+            cur = torch.where(unpack_xbits(o["mask_bits"], F), cur, torch.zeros_like(cur))
+        if o.get("sbwd_p") is not None:
+            P = unpack_any(o["sbwd_p"], pts, F)
+            cur = o["sbwd_scale"] * P * (cur - (cur * P).sum(-1, keepdim=True))
+        if o.get("store_in") is not None:
+            t = o["store_in"]
+            stored = unpack_any(t, pts, F)
+            _check(rep, f"{name}: stored input", stored, cur, t.dtype == torch.bfloat16, TOL_STEP)
+            cur = stored
+        if o.get("store_in_bits") is not None:
+            bits = unpack_xbits(o["store_in_bits"], F)
+            bad = (bits != (cur > 0)) & (cur.abs() > TOL_STEP * float(cur.abs().max()))
+            rep.add(f"{name}: ReLU bits of the input", float(bad.sum()), 0.5)
+        if o.get("img") is None:
+            continue
+        W = R(_op_weights(o, n, F))
+        y = torch.einsum("bpk,bnk->bpn", R(cur), W.expand(n, F, F))
+        if o.get("bias") is not None:
+            b = o["bias"].detach().cpu().double()
+            y = y + (b[:, None, :] if b.dim() == 2 else b)
+        if o.get("addend") is not None:
+            y = y + unpack32(o["addend"], pts, F)
+        if o.get("relu"):
+            y = y.clamp_min(0.0)
+        if o.get("softmax_n"):
+            c = o["softmax_n"]
+            P = torch.softmax(o.get("softmax_scale", 1.0) * y[..., :c], dim=-1)
+            y = torch.zeros_like(y)
+            y[..., :c] = P
+        if o.get("store_bits") is not None:
+            bits = unpack_xbits(o["store_bits"], F)
+            bad = (bits != (y > 0)) & (y.abs() > TOL_STEP * float(y.abs().max()))
+            rep.add(f"{name}: ReLU bits of the output", float(bad.sum()), 0.5)
+        if o.get("store_out") is not None:
+            t = o["store_out"]
+            stored = unpack_any(t, pts, F)
+            _check(rep, f"{name}: stored output", stored, y, t.dtype == torch.bfloat16, TOL_STEP)
+            cur = stored
+        else:
+            cur = y
+            rep.unforced += 1
+    if prog.tail is not None:
+        Wo, bo, rows = prog.tail
+        y = R(cur) @ R(Wo.detach().cpu().double()).t()
+        if bo is not None:
+            y = y + bo.detach().cpu().double()
+        _check(rep, f"{tag}output layer", rows.detach().cpu().double(), y, False, TOL_STEP)
+
+
+def walk_wgrad(rec, rep: Report, tag: str = "") -> None:
+    """The weight / key / value gradient jobs of a fused side: dW = dZ_stored^T A_stored (operands rounded where the launch rounds
+    them), db = the sum of the dZ buffer as stored."""
+    _, jobs, n, pts, bf16 = rec
+    R = r16 if bf16 else (lambda x: x)
+    for j, jb in enumerate(jobs):
+        N, K = jb["N"], jb["K"]
+        Fz, Fa = jb["dZ"].shape[2] * jb["dZ"].shape[4], jb["A"].shape[2] * jb["A"].shape[4]
+        dZ, A = unpack_any(jb["dZ"], pts, Fz)[..., :N], unpack_any(jb["A"], pts, Fa)[..., :K]
+        if jb.get("per_task"):
+            ref = torch.einsum("bpn,bpk->bnk", R(dZ), R(A))
+            got = unpack32(jb["dW"], N, jb["dW"].shape[2] * 4)[..., :K]
+        else:
+            ref = torch.einsum("bpn,bpk->nk", R(dZ), R(A))
+            got = jb["dW"].detach().cpu().double()[:N, :K]
+        rep.n_values += ref.numel()
+        rep.add(f"{tag}job {j} ({N} x {K}): weight gradient vs dZ_stored^T A_stored",
+                float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30), TOL_SUM)
+        if jb.get("db") is not None:
+            db = dZ.sum((0, 1))
+            rep.add(f"{tag}job {j}: bias gradient vs the sum of the stored dZ",
+                    float((jb["db"].detach().cpu().double()[:N] - db).abs().max()) / max(float(db.abs().max()), 1e-30), TOL_SUM)
+
+
 def chain_upstream(rec, i: int) -> bool:
     """Does a gradient continue below step i (the ``upstream_before`` of chain._ChainFn, re-derived from the record)."""
     chain, T = rec[1], rec[7]
@@ -404,6 +534,12 @@ def check_trace(trace, tag: str = "") -> Report:
     """Walk every chain execution of a ``chain.TRACE`` list (forward and backward records)."""
     rep = Report()
     for j, rec in enumerate(trace):
+        if rec[0] == "prog":
+            walk_program(rec[1], rep, f"{tag}launch {j} ({'b16' if rec[1].bf16 else 'x6'} program: {rec[1].tag}) ")
+            continue
+        if rec[0] == "wgrad":
+            walk_wgrad(rec, rep, f"{tag}launch {j} (fused side's gradient jobs) ")
+            continue
         name = f"{tag}chain {j} ({'bf16' if rec[5] else 'fp32'} instance) "
         if rec[0] == "fwd":
             walk_forward(rec, rep, name)

@@ -135,7 +135,8 @@ def test_bf16_mode_teacher_forced(name):
     trace = []
     _hip_bf16(case, inp, params, trace=trace)
     rep = _teacher_forced(trace, name)
-    assert any(rec[5] for rec in trace), "no chain ran on the bf16 instance"
+    assert any(rec[1].bf16 if rec[0] == "prog" else (rec[0] in ("fwd", "bwd") and rec[5]) for rec in trace), \
+        "nothing ran on the bf16 instances"
     for f in rep.flips:
         print("  flip:", f)
 
