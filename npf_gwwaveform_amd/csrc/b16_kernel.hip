@@ -9,27 +9,33 @@
 //   store_in   <- bf16(cur) as a PT16 tensor   (NPF_X6_STORE_IN_F32: cur itself as a PT32 tensor -- a dZ that is also an fp32 addend)
 //   store_out  <- bf16(cur) as a PT16 tensor   (NPF_X6_STORE_OUT_F32: cur itself, PT32 -- what a later addend / the model reads)
 //   sbwd_p     =  PT16 (the saved probabilities ARE bf16(P))
-// Against the three-term kernel a slab carries a third of the bytes per output row and a sixth of the matrix instructions, so a
-// wave owns a whole tile (32 points: every weight fragment read from LDS feeds two matrix instructions) and a slab holds 16 RB
-// output rows (one barrier per RB 16-row blocks).  Eight waves share one ring of three slabs.
+// Against the three-term kernel a slab carries a third of the bytes per output row and a sixth of the matrix instructions: a slab
+// holds 16 RB output rows (one barrier per RB 16-row blocks), a wave keeps nine LDS reads in flight ahead of its matrix
+// instructions, the slab's output blocks are stored one slab later (a slab ahead of the barrier that waits for them), and every
+// multiply's bias row is staged in LDS once per workgroup.  Eight waves of 16 points share one ring of three slabs.
 #include "x6_args.hpp"
+
+// Timing-only diagnostic builds (tools/fastbuild.sh b16_kernel OUT.so -DBP_NO_...): each removes one ingredient, results are
+// garbage, only the clock counts.  None is defined in the library build.
+//   BP_NO_MFMA no matrix instructions   BP_NO_FRAG no fragment / bias reads from LDS   BP_NO_DMA no slab DMA
+//   BP_NO_STORE no global stores of the ops   BP_NO_BARRIER no slab barriers / counted waits   BP_NO_EPI no block epilogues
 
 namespace npf {
 
-template <int KF, int RB>
+template <int KF, int RB, int NW_, int SLOTS>
 struct BpGeom {
-  static constexpr int NW = 8;
+  static constexpr int NW = NW_;
   static constexpr int NB = KF / 16;        // 16-feature blocks of an activation
   static constexpr int KS = KF / 32;        // k-steps per block row
   static constexpr int NS = NB / RB;        // slabs per multiply
   static constexpr int RowB = KF * 2;       // bytes of an image row
   static constexpr int SlabB = 16 * RB * RowB;
-  static constexpr int Slots = 3;
+  static constexpr int Slots = SLOTS;       // ring slots: Slots - 1 slabs in flight ahead of the one being multiplied
   static constexpr int RPP = 1024 / RowB;   // rows per 1 KiB DMA piece
   static constexpr int NPW = 16 * RB / RPP / NW;  // pieces per wave and slab
-  static constexpr int BiasB = 2 * KF * 4;
+  static constexpr int BiasB = NPF_X6_MAX_OPS * KF * 4;  // the bias rows of every multiply of the program
   static_assert(NB % RB == 0 && RB % 2 == 0 && NPW >= 1 && (16 * RB / RPP) % NW == 0, "slab geometry");
-  static_assert(NS >= 2, "two slabs in flight");
+  static_assert(NS >= 2 && (SLOTS == 2 || SLOTS == 3) && (NW_ == 4 || NW_ == 8), "ring geometry");
 };
 
 // round to bf16 and back (a value as the next multiply sees it)
@@ -50,14 +56,16 @@ __device__ __forceinline__ void bp_unpack(const xp_u32x4& t, f32x4& lo, f32x4& h
   hi[3] = __uint_as_float(t[3] & 0xffff0000u);
 }
 
-// NPG = 16-point groups per wave (2: a wave owns a tile; 1: half a tile -- small launches fill more CUs)
-template <int KF, int NPG, int RB>
-__global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
-  using G = BpGeom<KF, RB>;
+// NPG = 16-point groups per wave (1 in every instance the library launches: a wave owns half a tile; 2 = a whole tile).  NW_ = waves per workgroup sharing one slab ring, SLOTS
+// its slots: <.., 8, 3> one workgroup per CU; <.., 4, 2> two workgroups per CU, out of step with each other -- one multiplies
+// while the other sits in an op's input side or at a barrier.
+template <int KF, int NPG, int RB, int NW_, int SLOTS>
+__global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_program_kernel(const XpArgs a) {
+  using G = BpGeom<KF, RB, NW_, SLOTS>;
   constexpr int NB = G::NB, KS = G::KS, NS = G::NS, NW = G::NW, Slots = G::Slots, NPW = G::NPW;
-  constexpr int TPW = NPG == 2 ? 8 : 4;  // tiles per workgroup
+  constexpr int LA = Slots - 1;             // slabs in flight ahead
+  constexpr int TPW = NPG * NW / 2;         // tiles per workgroup
   static_assert(NB <= 16, "a lane's ReLU bits are one 64-bit word");
-  static_assert(NPW <= KS, "one slab piece per k-step");
   __shared__ __attribute__((aligned(16))) char smem[Slots * G::SlabB + G::BiasB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,6 +86,9 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
     task = valid ? (int)(t / a.tiles_per_task) : 0;
     t_in = valid ? (int)(t - (long)task * a.tiles_per_task) : 0;
   }
+#ifdef BP_NO_STORE
+  valid = valid && a.n_ops > 1000;  // (never true: the stores stay in the code, none executes)
+#endif
   // (a wave without a tile still streams slabs and meets barriers; it loads tile 0 and stores nothing)
   const long tile = valid ? (long)task * a.tiles_per_task + t_in : 0;
   if (a.wgs_per_task == 0) task = 0;  // (flat launches share every weight)
@@ -95,18 +106,21 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
     return (xp_u32x4*)((char*)const_cast<float*>(base) + tile_off * 2 + (size_t)(st * 2048 + 256 * pg) + lane16);
   };
 
-  // slab DMA: 16 RB / RPP pieces of 1 KiB, piece q = rows RPP q ..; wave w takes q = w + 8 n.  Chunk c of row r sits at position
-  // c ^ (r & 15) of its row (the swizzle is applied to the SOURCE address); RPP * 8 is a multiple of 16, so a wave's lane offset
-  // is the same for all its pieces
+  // slab DMA: 16 RB / RPP pieces of 1 KiB, piece q = rows RPP q ..; wave w takes q = w + NW n.  Chunk c of row r sits at position
+  // c ^ (r & 15) of its row (the swizzle is applied to the SOURCE address)
   constexpr int LPR = 64 / G::RPP;  // lanes per row of a piece
-  const unsigned dma_lane = (unsigned)((lane / LPR) * G::RowB + (((lane % LPR) ^ ((G::RPP * wave + lane / LPR) & 15)) << 4));
+  const int l_row = lane / LPR, l_pos = lane % LPR;
   const int n_slabs = a.n_mm * NS;
   auto mm_base = [&](int j) { return a.mm_img[j] + (size_t)task * a.mm_stride[j]; };
   // piece n of this wave's share of the slab whose first image row is ``rows``
   auto dma_piece = [&](const char* img, int rows, char* slot, int n) {
+#ifdef BP_NO_DMA
+    return;
+#endif
     const int r0 = G::RPP * (wave + NW * n);
     const char* base = img + (size_t)(rows + r0) * G::RowB;
     asm volatile("" : "+s"(base));
+    const unsigned dma_lane = (unsigned)(l_row * G::RowB + ((l_pos ^ ((r0 + l_row) & 15)) << 4));
     xp_dma16(base + dma_lane, slot + r0 * G::RowB);
   };
   auto dma_slab = [&](int S, char* slot) {
@@ -119,7 +133,20 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
   float* bias_lds = (float*)(smem + Slots * G::SlabB);
 
   if (n_slabs > 0) dma_slab(0, smem);
-  if (n_slabs > 1) dma_slab(1, smem + G::SlabB);
+  if (LA > 1 && n_slabs > 1) dma_slab(1, smem + G::SlabB);
+  // every multiply's bias row goes to LDS once, here (read back per 16-row block behind the barriers of the slab loop): no op
+  // starts by waiting for a global load
+  {
+    int j = 0;
+    for (int l = 0; l < a.n_ops; ++l) {
+      const npf_x6_op_t& o = a.op[l];
+      if (o.w_img == nullptr) continue;
+      for (int i = tid; i < KF; i += NW * 64)
+        bias_lds[j * KF + i] = o.bias != nullptr ? o.bias[(size_t)task * o.bias_task_stride + i] : 0.f;
+      ++j;
+    }
+  }
+
   int slot = 0, S0 = 0, jm = 0;
   f32x4 cur[NPG][NB];
 #pragma unroll
@@ -222,8 +249,6 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
     if (o.w_img == nullptr) continue;
 
     // ---------------------------------------------------------------- the multiply
-    for (int i = tid; i < KF; i += NW * 64)
-      bias_lds[(jm & 1) * KF + i] = o.bias != nullptr ? o.bias[(size_t)task * o.bias_task_stride + i] : 0.f;
     // the input rounded to bf16 (the B operands), once per op
     xp_u32x4 tb[NPG][KS];
 #pragma unroll
@@ -243,27 +268,59 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
     const bool post = o.softmax_n > 0;  // (the stores then follow the softmax)
     const float* const out = (o.store_out != nullptr && valid && !post) ? o.store_out : nullptr;  // (wave-uniform)
     const bool out32 = (oflags & NPF_X6_STORE_OUT_F32) != 0;
-    const unsigned bias_l = lds0 + Slots * G::SlabB + (jm & 1) * (KF * 4) + g * 16;
+    const unsigned bias_l = lds0 + Slots * G::SlabB + jm * (KF * 4) + g * 16;
     const bool relu = o.relu != 0;
     unsigned pos_lo[NPG], pos_hi[NPG];
 #pragma unroll
     for (int pg = 0; pg < NPG; ++pg) pos_lo[pg] = pos_hi[pg] = 0u;
+    // the RB output blocks of slab s leave for store_out (fp32 blocks, or pairs of blocks as PT16 rows)
+    auto store_blocks = [&](int s) {
+      if (out == nullptr) return;
+#pragma unroll
+      for (int pg = 0; pg < NPG; ++pg) {
+        if (out32) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) __builtin_nontemporal_store(cur[pg][s * RB + rb], pt32(out, pg, s * RB + rb));
+        } else {
+#pragma unroll
+          for (int h = 0; h < RB / 2; ++h) {
+            const int st = (s * RB) / 2 + h;
+            xp_u32x4 t;
+            bp_pack(cur[pg][2 * st], cur[pg][2 * st + 1], t);
+            __builtin_nontemporal_store(t, pt16(out, pg, st));
+          }
+        }
+      }
+    };
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int S = S0 + s;
-      // slab S has landed for everyone, everyone is done with slab S - 1 (whose slot slab S + 2 goes into); the NPW pieces of
-      // slab S + 1 may stay in flight (vector-memory operations retire in order)
-      if (S + 1 < n_slabs) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW) : "memory");
+      // slab S has landed for everyone, everyone is done with slab S - 1 (whose slot slab S + LA goes into).  The pieces of the
+      // LA - 1 later slabs may stay in flight (vector-memory operations retire in order; this wave's stores are issued BEFORE the
+      // pieces at the same point, so by now they are a slab old)
+      // (an op's first barrier: its addend -- 16 NPG loads, the newest vector-memory operations of this wave -- may stay in flight
+      // too; the blocks' epilogues wait for what they add)
+#ifdef BP_NO_BARRIER
+      if (false) {}
+      else
+#endif
+      if (s == 0 && has_add && NB * NPG <= 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NB * NPG) : "memory");
+      else if (LA > 1 && S + 1 < n_slabs) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((LA - 1) * NPW) : "memory");
+#ifdef BP_NO_BARRIER
+      else if (false) {}
+#endif
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const bool more = S + 2 < n_slabs;
-      char* const nslot = smem + ((slot + 2) % Slots) * G::SlabB;
+      const bool more = S + LA < n_slabs;
+      char* const nslot = smem + ((slot + LA) % Slots) * G::SlabB;
       const unsigned sl = lds0 + slot * G::SlabB + lane_row;
-      // Slab S + 2 goes into the slot slab S - 1 has left.  Its pieces are issued HERE, where none of this wave's LDS reads is
-      // outstanding (csrc/x6_kernel.hip: vector-memory instructions issued while fragment reads were in flight gave sporadic wrong
-      // results); from here to the end of the slab the wave keeps LDS reads in flight all the time.
+      // HERE none of this wave's LDS reads is outstanding (csrc/x6_kernel.hip: vector-memory instructions issued while fragment
+      // reads were in flight gave sporadic wrong results); from here to the end of the slab the wave keeps LDS reads in flight.
+      // So the previous slab's output blocks are stored now -- a whole slab ahead of the barrier that waits for them -- and then
+      // slab S + LA is sent into the slot slab S - 1 has left.
+      if (s > 0) store_blocks(s - 1);
       if (more) {
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) dma_piece(s + 2 < NS ? img0 : img1, ((s + 2) % NS) * 16 * RB, nslot, n);
+        for (int n = 0; n < NPW; ++n) dma_piece(s + LA < NS ? img0 : img1, ((s + LA) % NS) * 16 * RB, nslot, n);
       }
       // The slab's LDS reads in order: per 16-row block its bias row, then its KS weight fragments.  W of them are in flight ahead
       // of the matrix instructions (a ring of W + 1 registers: a read is issued into the register consumed one step earlier);
@@ -273,11 +330,17 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
       auto rd = [&](int j) {
         const int rb = j / (KS + 1), q = j % (KS + 1);
         const unsigned addr = q == 0 ? bias_l + 64 * (s * RB + rb) : sl + rb * 16 * G::RowB + (((4 * (q - 1) + g) ^ p) << 4);
+#ifdef BP_NO_FRAG
+        asm volatile("" : "=v"(ring[j % (W + 1)]) : "v"(addr));
+#else
         asm volatile("ds_read_b128 %0, %1" : "=v"(ring[j % (W + 1)]) : "v"(addr));
+#endif
       };
 #pragma unroll
       for (int j = 0; j < W; ++j) rd(j);
-      f32x4 acc[NPG][2];   // two accumulators per point group (even / odd k-steps): no back-to-back dependent MFMAs
+      // two accumulators per point group (even / odd k-steps): no back-to-back dependent matrix instructions
+      constexpr int NA = 2;
+      f32x4 acc[NPG][NA];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int rb = j / (KS + 1), q = j % (KS + 1), sb = s * RB + rb;
@@ -291,20 +354,28 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
 #pragma unroll
           for (int pg = 0; pg < NPG; ++pg) {
             acc[pg][0] = __builtin_bit_cast(f32x4, f);  // (the bias row is the same for every point group)
-            acc[pg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (NA == 2) acc[pg][NA - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
         } else {
           const int st = q - 1;
 #pragma unroll
           for (int pg = 0; pg < NPG; ++pg)
-            acc[pg][st & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xp_bf16x8, f),
-                                                                      __builtin_bit_cast(xp_bf16x8, tb[pg][st]), acc[pg][st & 1], 0, 0, 0);
+#ifdef BP_NO_MFMA
+            asm volatile("" : "+v"(acc[pg][st & (NA - 1)]) : "v"(f), "v"(tb[pg][st]));
+#else
+            acc[pg][st & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(xp_bf16x8, f), __builtin_bit_cast(xp_bf16x8, tb[pg][st]), acc[pg][st & (NA - 1)], 0, 0, 0);
+#endif
         }
         if (j + W < NR) rd(j + W);
+#ifdef BP_NO_EPI
+        if (q == KS && a.n_ops > 1000) {
+#else
         if (q == KS) {
+#endif
 #pragma unroll
           for (int pg = 0; pg < NPG; ++pg) {
-            f32x4 r = acc[pg][0] + acc[pg][1];
+            f32x4 r = NA == 2 ? acc[pg][0] + acc[pg][NA - 1] : acc[pg][0];
             if (has_add) r += cur[pg][sb];
             if (relu) {
 #pragma unroll
@@ -316,26 +387,9 @@ __global__ __launch_bounds__(512, 1) void b16_program_kernel(const XpArgs a) {
           }
         }
       }
-      // the slab's RB output blocks leave here, where no LDS read of this wave is outstanding
-      if (out != nullptr) {
-#pragma unroll
-        for (int pg = 0; pg < NPG; ++pg) {
-          if (out32) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) __builtin_nontemporal_store(cur[pg][s * RB + rb], pt32(out, pg, s * RB + rb));
-          } else {
-#pragma unroll
-            for (int h = 0; h < RB / 2; ++h) {
-              const int st = (s * RB) / 2 + h;
-              xp_u32x4 t;
-              bp_pack(cur[pg][2 * st], cur[pg][2 * st + 1], t);
-              __builtin_nontemporal_store(t, pt16(out, pg, st));
-            }
-          }
-        }
-      }
       slot = (slot + 1) % Slots;
     }
+    store_blocks(NS - 1);
     S0 += NS;
     ++jm;
     // ---------------------------------------------------------------- output side behind the last slab
@@ -437,20 +491,24 @@ extern "C" int npf_b16_run(const npf_x6_op_t* ops, int32_t n_ops, const float* o
   if (rc != NPF_OK) return rc;
   for (int l = 0; l < n_ops; ++l)
     if (ops[l].mask != nullptr) return NPF_EINVAL;  // (ReLU masks are bits here)
-  // 1 = a wave owns half a tile (16 points; four tiles per workgroup), 2 = a whole tile (eight tiles per workgroup: every weight
-  // fragment feeds two matrix instructions, but 256 registers do not hold it -- the instance spills; kept for A-B runs)
-  int var = variant;
-  if (var == 0) var = 1;
-  const int tpw = var == 2 ? 8 : 4;
+  // 1 = eight waves of 16 points share a ring of three slabs, one workgroup per CU (the library's choice); 2 = four waves of 16
+  // points and a ring of two slabs, two workgroups per CU.  (Measured on config 3, target side forward: 2.60 ms (1), 2.97 (2);
+  // 32 points per wave -- every weight fragment feeding two matrix instructions -- 4.17 at two waves per SIMD (256 registers do
+  // not hold it: spills in the slab loop) and 3.35 at one wave per SIMD with 404 registers)
+  const int var = variant == 0 ? 1 : variant;
+  const int tpw = var == 2 ? 2 : 4;
   a.wgs_per_task = per_task ? (tiles_per_task + tpw - 1) / tpw : 0;
   const int n_wg = per_task ? n_tasks * a.wgs_per_task : (a.total_tiles + tpw - 1) / tpw;
   a.xcd_remap = (per_task && (n_wg % 8) == 0 && a.wgs_per_task > 1) ? 1 : 0;
-  const dim3 grid(n_wg), block(512);
+  const dim3 grid(n_wg);
   hipStream_t st = (hipStream_t)stream;
-  if (width == 256 && var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<256, 2, 4>), grid, block, 0, st, a);
-  else if (width == 256) hipLaunchKernelGGL((npf::b16_program_kernel<256, 1, 4>), grid, block, 0, st, a);
-  else if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<128, 2, 4>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((npf::b16_program_kernel<128, 1, 4>), grid, block, 0, st, a);
+  if (width == 256) {
+    if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<256, 1, 4, 4, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((npf::b16_program_kernel<256, 1, 4, 8, 3>), grid, dim3(512), 0, st, a);
+  } else {
+    if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<128, 1, 4, 4, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((npf::b16_program_kernel<128, 1, 4, 8, 3>), grid, dim3(512), 0, st, a);
+  }
   NPF_CHECK_LAUNCH();
   return NPF_OK;
 }

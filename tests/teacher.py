@@ -422,10 +422,11 @@ def walk_program(prog, rep: Report, tag: str = "") -> None:
     n, pts, F = prog.n_tasks, prog.tiles * 32, prog.width
     R = r16 if prog.bf16 else (lambda x: x)
     cur = None
+    forced = True   # cur is a tensor the launch read or stored (not a value this walker computed)
     for l, o in enumerate(prog.ops):
         name = f"{tag}op {l}"
         if o.get("in_pt") is not None:
-            cur = unpack32(o["in_pt"], pts, F)
+            cur, forced = unpack32(o["in_pt"], pts, F), True
         if o.get("in_rows") is not None:
             rows, w = o["in_rows"].detach().cpu().double(), o["in_w"].detach().cpu().double()
             v = rows @ w
@@ -435,24 +436,26 @@ def walk_program(prog, rep: Report, tag: str = "") -> None:
                 v = v.clamp_min(0.0)
             cur = torch.zeros(n, pts, F, dtype=torch.float64)
             cur[..., :v.shape[-1]] = v
+            forced = False
         if o.get("pre_add") is not None:
-            cur = cur + unpack32(o["pre_add"], pts, F)
+            cur, forced = cur + unpack32(o["pre_add"], pts, F), False
         if o.get("mask_bits") is not None:
             cur = torch.where(unpack_xbits(o["mask_bits"], F), cur, torch.zeros_like(cur))
         if o.get("sbwd_p") is not None:
             P = unpack_any(o["sbwd_p"], pts, F)
-            cur = o["sbwd_scale"] * P * (cur - (cur * P).sum(-1, keepdim=True))
+            cur, forced = o["sbwd_scale"] * P * (cur - (cur * P).sum(-1, keepdim=True)), False
         if o.get("store_in") is not None:
             t = o["store_in"]
             stored = unpack_any(t, pts, F)
             _check(rep, f"{name}: stored input", stored, cur, t.dtype == torch.bfloat16, TOL_STEP)
-            cur = stored
+            cur, forced = stored, True
         if o.get("store_in_bits") is not None:
             bits = unpack_xbits(o["store_in_bits"], F)
             bad = (bits != (cur > 0)) & (cur.abs() > TOL_STEP * float(cur.abs().max()))
             rep.add(f"{name}: ReLU bits of the input", float(bad.sum()), 0.5)
         if o.get("img") is None:
             continue
+        rep.unforced += 0 if forced else 1  # (a multiply whose rounded input no stored tensor pins)
         W = R(_op_weights(o, n, F))
         y = torch.einsum("bpk,bnk->bpn", R(cur), W.expand(n, F, F))
         if o.get("bias") is not None:
@@ -475,10 +478,9 @@ def walk_program(prog, rep: Report, tag: str = "") -> None:
             t = o["store_out"]
             stored = unpack_any(t, pts, F)
             _check(rep, f"{name}: stored output", stored, y, t.dtype == torch.bfloat16, TOL_STEP)
-            cur = stored
+            cur, forced = stored, True
         else:
-            cur = y
-            rep.unforced += 1
+            cur, forced = y, False
     if prog.tail is not None:
         Wo, bo, rows = prog.tail
         y = R(cur) @ R(Wo.detach().cpu().double()).t()

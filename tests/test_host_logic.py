@@ -285,7 +285,7 @@ def test_hot_kernel_instances_do_not_spill():
 
     with tempfile.TemporaryDirectory() as tmp:
         spills = {}
-        for src in ("chain_kernel.hip", "wgrad_kernel.hip", "x6_kernel.hip"):
+        for src in ("chain_kernel.hip", "wgrad_kernel.hip", "x6_kernel.hip", "b16_kernel.hip"):
             out = os.path.join(tmp, src + ".s")
             subprocess.run([_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                             "-I", _build.CSRC, "--cuda-device-only", "-S", os.path.join(_build.CSRC, src), "-o", out],
@@ -306,6 +306,9 @@ def test_hot_kernel_instances_do_not_spill():
     for inst, most in (("x6_program_kernelILi256ELi1ELi8ELi2E", 8), ("x6_program_kernelILi256ELi1ELi4ELi2E", 8),
                        ("x6_program_kernelILi128ELi1ELi4ELi2E", 0), ("x6_program_kernelILi256ELi2ELi4ELi2E", 0),
                        ("x6_program_kernelILi512ELi1ELi4ELi2E", 0)):
+        assert len(one(inst)) == 1 and spills[one(inst)[0]] <= most, (inst, spills)
+    # the b16 program kernel (BASELINE config 3): the instances the library launches by default
+    for inst, most in (("b16_program_kernelILi256ELi1ELi4ELi8ELi3E", 8), ("b16_program_kernelILi128ELi1ELi4ELi8ELi3E", 0)):
         assert len(one(inst)) == 1 and spills[one(inst)[0]] <= most, (inst, spills)
 
 
