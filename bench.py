@@ -353,13 +353,17 @@ def profile_launches(step, n_prof: int, rank: int, sync, CH):
     if "mlp_x6_kernel" in kernels:
         kernels["mlp_x6_kernel"]["note"] = ("npf_mlp_x6_run: the 256 -> 256 layers of the flat MLPs (decoder resizer + merge + hidden, "
                                             "XY-encoder flat module), fp32 operands as three exact bf16 terms, six bf16 MFMAs per "
-                                            "product group -- fp32 results on the bf16 pipe (DESIGN.md 3.2 / 3.7); NPF_NO_MLP_X6=1 "
+                                            "product group -- fp32 results on the bf16 pipe (DESIGN.md 3.4); NPF_NO_MLP_X6=1 "
                                             "keeps them in the fp32 chains")
     if "x6_program_kernel" in kernels:
         kernels["x6_program_kernel"]["note"] = ("npf_x6_run: a whole side of the model per launch (x-encoder, scaled-dot attention, "
                                                 "decoder / XY-encoder; forward or dgrad), every product an fp32 product on the bf16 "
                                                 "pipe (three exact bf16 terms per operand, six v_mfma_f32_16x16x32_bf16 per product "
-                                                "group, fp32 accumulation; DESIGN.md 3.8); NPF_NO_X6_FUSED=1 = the round-2 launches")
+                                                "group, fp32 accumulation; DESIGN.md 3.1); NPF_NO_X6_FUSED=1 = the round-2 launches")
+    if "b16_program_kernel" in kernels:
+        kernels["b16_program_kernel"]["note"] = ("npf_b16_run: a whole side of the model per launch in the bf16 compute mode (one "
+                                                 "v_mfma_f32_16x16x32_bf16 per product group, fp32 accumulation, backward-only "
+                                                 "tensors as bf16 tiles; DESIGN.md 8.1); NPF_NO_B16_FUSED=1 = the bf16 chain launches")
     if "wgrad_kernel" in kernels and CH.COMPUTE_DTYPE != "bf16" and CH.WGRAD_X6:
         # (the rate can exceed the fp32 MFMA peak: these launches run on the bf16 matrix pipe)
         kernels["wgrad_kernel"]["note"] = ("wgrad_x6_kernel: fp32 operands split exactly into three bf16 terms, six "
@@ -482,7 +486,7 @@ def main_decode(args, rank, world, dev, sync):
             "ms_per_step_spread": spread,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation "
-                      "-- f32 results, DESIGN.md 3.2 / 3.8)" if "x6_program_kernel" in kernels else "f32"),
+                      "-- f32 results, DESIGN.md 3.1 / 3.2)" if "x6_program_kernel" in kernels else "f32"),
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 5: decode(X_trgt_enc, R_trgt) only, {r}-wide {L}-layer decoder, {T} target "
                                    f"points per waveform, {B} waveforms per GPU, fp32, encoder outputs resident in HBM "
@@ -593,7 +597,7 @@ def main_train(args, rank, world, dev, sync, rehearsal):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32" if os.environ.get("NPF_NO_WGRAD_X6", "0") == "1" and os.environ.get("NPF_NO_MLP_X6", "0") == "1" else
-                      "f32 (every contraction of the step: fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation -- f32 results, DESIGN.md 3.2 / 3.8; the 1-4-wide first / last layers: f32 FMAs)"
+                      "f32 (every contraction of the step: fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation -- f32 results, DESIGN.md 3.1 / 3.2; the 1-4-wide first / last layers: f32 FMAs)"
                       if os.environ.get("NPF_NO_X6_FUSED", "0") != "1" and args.attention == "scaledot" and args.model == "attncnp" and args.r == 256 else
                       "f32 (attention / first / last layers: v_mfma_f32_16x16x4_f32; 256-wide MLP layers and weight gradients: fp32 operands as three exact bf16 terms, six v_mfma_f32_16x16x32_bf16 per product group, f32 accumulation)")
             if args.dtype == "fp32" else "bf16 (products in MLP stacks, attention and weight gradients; f32 accumulation, epilogues, outputs, optimizer)",

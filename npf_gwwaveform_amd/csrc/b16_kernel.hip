@@ -22,6 +22,21 @@
 
 namespace npf {
 
+#ifdef NPF_STAMPS
+// Diagnostic build only (tools/stamp_probe_b16.py): per-phase cycle sums of wave 0 of workgroup 0, in a buffer nothing else reads.
+__device__ unsigned long long g_stamps_b16[16];
+__device__ __forceinline__ unsigned long long bp_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define BP_STAMP(i) { const unsigned long long t__ = bp_stamp(); st_sum[i] += t__ - st_last; st_last = t__; }
+#else
+#define BP_STAMP(i)
+#endif
+
 template <int KF, int RB, int NW_, int SLOTS>
 struct BpGeom {
   static constexpr int NW = NW_;
@@ -66,7 +81,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   constexpr int LA = Slots - 1;             // slabs in flight ahead
   constexpr int TPW = NPG * NW / 2;         // tiles per workgroup
   static_assert(NB <= 16, "a lane's ReLU bits are one 64-bit word");
-  __shared__ __attribute__((aligned(16))) char smem[Slots * G::SlabB + G::BiasB];
+  __shared__ __attribute__((aligned(16))) char smem[Slots * G::SlabB + G::BiasB + KF * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
@@ -131,22 +146,28 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lane_row = (unsigned)(p * G::RowB);
   float* bias_lds = (float*)(smem + Slots * G::SlabB);
+  f32x4* out_w_lds = (f32x4*)(smem + Slots * G::SlabB + G::BiasB);
 
   if (n_slabs > 0) dma_slab(0, smem);
   if (LA > 1 && n_slabs > 1) dma_slab(1, smem + G::SlabB);
-  // every multiply's bias row goes to LDS once, here (read back per 16-row block behind the barriers of the slab loop): no op
-  // starts by waiting for a global load
+  // every multiply's bias row goes to LDS once, here (read back per 16-row block behind the barriers of the slab loop), and so does
+  // the matrix of the F -> 4 layer behind the program: no op starts by waiting for a global load.  All loads first, then the stores.
   {
-    int j = 0;
-    for (int l = 0; l < a.n_ops; ++l) {
-      const npf_x6_op_t& o = a.op[l];
-      if (o.w_img == nullptr) continue;
-      for (int i = tid; i < KF; i += NW * 64)
-        bias_lds[j * KF + i] = o.bias != nullptr ? o.bias[(size_t)task * o.bias_task_stride + i] : 0.f;
-      ++j;
+    constexpr int NE = NPF_X6_MAX_OPS * KF / (NW * 64);
+    float v[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = tid + k * (NW * 64), j = e / KF, i = e % KF;
+      const float* b = j < a.n_mm ? a.mm_bias[j] : nullptr;
+      v[k] = b != nullptr ? b[(size_t)task * a.mm_bias_stride[j] + i] : 0.f;
     }
+    f32x4 w = {0.f, 0.f, 0.f, 0.f};
+    if (a.out_rows != nullptr && tid < KF) w = ((const f32x4*)a.out_w)[tid];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) bias_lds[tid + k * (NW * 64)] = v[k];
+    if (tid < KF) out_w_lds[tid] = w;
   }
-
+  if (n_slabs == 0) __syncthreads();  // (otherwise the first slab's barrier publishes them)
   int slot = 0, S0 = 0, jm = 0;
   f32x4 cur[NPG][NB];
 #pragma unroll
@@ -154,9 +175,15 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
 #pragma unroll
     for (int b = 0; b < NB; ++b) cur[pg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef NPF_STAMPS
+  unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = bp_stamp();
+  const unsigned long long st_first = st_last;
+#endif
   for (int l = 0; l < a.n_ops; ++l) {
     const npf_x6_op_t& o = a.op[l];
     const int oflags = o.reserved[0];
+    BP_STAMP(0)  // loop back edge, op fields
     // ---------------------------------------------------------------- input side
 #pragma unroll
     for (int pg = 0; pg < NPG; ++pg) {
@@ -246,6 +273,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
         o.store_in_bits[bits_off + 64 * pg + lane] = ((unsigned long long)whi << 32) | wlo;
       }
     }
+    BP_STAMP(1)  // input side (loads, prologue, mask, softmax backward, stores)
     if (o.w_img == nullptr) continue;
 
     // ---------------------------------------------------------------- the multiply
@@ -263,6 +291,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
 #pragma unroll
         for (int b = 0; b < NB; ++b) cur[pg][b] = *pt32(o.addend, pg, b);
     }
+    BP_STAMP(2)  // pack, addend loads
     const char* const img0 = mm_base(jm);
     const char* const img1 = mm_base(jm + 1 < a.n_mm ? jm + 1 : jm);
     const bool post = o.softmax_n > 0;  // (the stores then follow the softmax)
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
       // slab S has landed for everyone, everyone is done with slab S - 1 (whose slot slab S + LA goes into).  The pieces of the
       // LA - 1 later slabs may stay in flight (vector-memory operations retire in order; this wave's stores are issued BEFORE the
       // pieces at the same point, so by now they are a slab old)
-      // (an op's first barrier: its addend -- 16 NPG loads, the newest vector-memory operations of this wave -- may stay in flight
+      // (an op's first barrier: its addend -- NB NPG loads, the newest vector-memory operations of this wave -- may stay in flight
       // too; the blocks' epilogues wait for what they add)
 #ifdef BP_NO_BARRIER
       if (false) {}
@@ -310,6 +339,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
       else if (false) {}
 #endif
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      BP_STAMP(3)  // counted wait + barrier
       const bool more = S + LA < n_slabs;
       char* const nslot = smem + ((slot + LA) % Slots) * G::SlabB;
       const unsigned sl = lds0 + slot * G::SlabB + lane_row;
@@ -322,6 +352,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
 #pragma unroll
         for (int n = 0; n < NPW; ++n) dma_piece(s + LA < NS ? img0 : img1, ((s + LA) % NS) * 16 * RB, nslot, n);
       }
+      BP_STAMP(4)  // stores of the previous slab, slab pieces
       // The slab's LDS reads in order: per 16-row block its bias row, then its KS weight fragments.  W of them are in flight ahead
       // of the matrix instructions (a ring of W + 1 registers: a read is issued into the register consumed one step earlier);
       // LDS reads return in order, so read j has landed once at most min(W - 1, NR - 1 - j) later ones are outstanding.
@@ -387,9 +418,11 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
           }
         }
       }
+      BP_STAMP(5)  // reads, matrix instructions, epilogues
       slot = (slot + 1) % Slots;
     }
     store_blocks(NS - 1);
+    BP_STAMP(6)  // the last slab's stores
     S0 += NS;
     ++jm;
     // ---------------------------------------------------------------- output side behind the last slab
@@ -444,13 +477,11 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
     }
   }
 
+  BP_STAMP(7)  // softmax / ReLU bits behind the last op
   if (a.out_rows != nullptr) {
     // an F -> 4 layer on the registers the program leaves (the decoder's output layer, mlp.py:109), its input rounded to bf16
     // like every layer's (the caller hands the bf16-rounded matrix): fp32 dot products, summed over the point's four lanes
-    __syncthreads();
-    f32x4* wl = (f32x4*)smem;
-    for (int i = tid; i < KF; i += NW * 64) wl[i] = ((const f32x4*)a.out_w)[i];
-    __syncthreads();
+    const f32x4* wl = out_w_lds;  // (staged at the start of the workgroup, behind every barrier since)
 #pragma unroll
     for (int pg = 0; pg < NPG; ++pg) {
       f32x4 r = {0.f, 0.f, 0.f, 0.f};
@@ -477,9 +508,22 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
       if (valid && g == 0) ((f32x4*)a.out_rows)[row_off + 16 * pg + p] = r;
     }
   }
+#ifdef NPF_STAMPS
+  BP_STAMP(8)  // the F -> 4 layer
+  if (blockIdx.x == 0 && tid == 0) {
+    for (int i = 0; i < 10; ++i) g_stamps_b16[i] = st_sum[i];
+    g_stamps_b16[10] = st_last - st_first;
+  }
+#endif
 }
 
 }  // namespace npf
+
+#ifdef NPF_STAMPS
+extern "C" int npf_debug_stamps_b16(unsigned long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(npf::g_stamps_b16), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int npf_b16_run(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
                            int32_t n_tasks, int32_t tiles_per_task, int32_t per_task, int32_t width, int32_t variant, void* stream) {
@@ -494,7 +538,7 @@ extern "C" int npf_b16_run(const npf_x6_op_t* ops, int32_t n_ops, const float* o
   // 1 = eight waves of 16 points share a ring of three slabs, one workgroup per CU (the library's choice); 2 = four waves of 16
   // points and a ring of two slabs, two workgroups per CU.  (Measured on config 3, target side forward: 2.60 ms (1), 2.97 (2);
   // 32 points per wave -- every weight fragment feeding two matrix instructions -- 4.17 at two waves per SIMD (256 registers do
-  // not hold it: spills in the slab loop) and 3.35 at one wave per SIMD with 404 registers; DESIGN.md 3.2.)
+  // not hold it: spills in the slab loop) and 3.35 at one wave per SIMD with 404 registers; DESIGN.md 8.1.)
   const int var = variant == 0 ? 1 : variant;
   const int tpw = var == 2 ? 2 : 4;
   a.wgs_per_task = per_task ? (tiles_per_task + tpw - 1) / tpw : 0;

@@ -12,6 +12,8 @@ struct XpArgs {
   npf_x6_op_t op[NPF_X6_MAX_OPS];
   const char* mm_img[NPF_X6_MAX_OPS];  // the multiplies of the program in order (what the slab stream walks)
   int64_t mm_stride[NPF_X6_MAX_OPS];
+  const float* mm_bias[NPF_X6_MAX_OPS];  // their bias rows (or null) and per-task strides in floats
+  int64_t mm_bias_stride[NPF_X6_MAX_OPS];
   const float* out_w;
   const float* out_b;
   float* out_rows;
@@ -82,6 +84,8 @@ inline int xp_fill_args(const npf_x6_op_t* ops, int32_t n_ops, const float* out_
     if (o.w_img != nullptr) {
       a.mm_img[a.n_mm] = (const char*)o.w_img;
       a.mm_stride[a.n_mm] = o.w_task_stride;
+      a.mm_bias[a.n_mm] = o.bias;
+      a.mm_bias_stride[a.n_mm] = o.bias_task_stride;
       ++a.n_mm;
     }
   }
@@ -89,6 +93,8 @@ inline int xp_fill_args(const npf_x6_op_t* ops, int32_t n_ops, const float* out_
   for (int j = a.n_mm; j < NPF_X6_MAX_OPS; ++j) {
     a.mm_img[j] = a.n_mm ? a.mm_img[0] : nullptr;
     a.mm_stride[j] = 0;
+    a.mm_bias[j] = nullptr;
+    a.mm_bias_stride[j] = 0;
   }
   a.out_w = out_w;
   a.out_b = out_b;

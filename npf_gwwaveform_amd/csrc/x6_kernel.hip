@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KF * NPG <= 256) ? 2 : 1) void
       // slab S + LA goes into the slot slab S - 1 has left.  Its pieces are issued one per k-step, each at a point where none of
       // this wave's LDS reads is outstanding.  (Measured, round 3: a vector-memory instruction -- slab piece or store -- issued
       // between the matrix instructions while fragment reads were in flight gave sporadic wrong results in single waves at full
-      // grid sizes, counted or full waits alike; issued at these points never.  DESIGN.md 3.8.)
+      // grid sizes, counted or full waits alike; issued at these points never.  DESIGN.md 3.1.)
       const bool more = S + LA < n_slabs;
       char* const nslot = smem + ((slot + LA) % Slots) * G::SlabB;
       const unsigned sl = lds0 + slot * G::SlabB + lane_row;
@@ -772,7 +772,7 @@ extern "C" int npf_x6_run_ex(const npf_x6_op_t* ops, int32_t n_ops, const float*
   if (rc != NPF_OK) return rc;
   // 256 features: 1 = a wave owns half a tile, four waves per workgroup, two workgroups per CU; 2 = a wave owns a whole tile (one
   // wave per SIMD); 3 = as 1 with eight waves per workgroup sharing one slab ring.  The library's choice is
-  // NPF_X6_DEFAULT_VARIANT (measured on the config-2 train step: 3 -- 6.45 ms against 6.62 (1) and 7.85 (2), DESIGN.md 3.8)
+  // NPF_X6_DEFAULT_VARIANT (measured on the config-2 train step: 3 -- 6.45 ms against 6.62 (1) and 7.85 (2), DESIGN.md 3.1)
   const int var = width == 256 ? (variant == 0 ? NPF_X6_DEFAULT_VARIANT : variant) : 1;
   const int npg = var == 2 ? 2 : 1;
   const int tpw = var == 1 ? 2 : 4;

@@ -3,7 +3,7 @@
 launch forward and one launch of their dgrad, weight gradients through the usual ``run_wgrad`` jobs.
 
 The arithmetic is fp32: every operand is split exactly into three bf16 terms and six of the nine cross products are
-accumulated in fp32 (DESIGN.md 3.2).  Nothing here computes on the CPU.
+accumulated in fp32 (DESIGN.md 3.4).  Nothing here computes on the CPU.
 """
 from __future__ import annotations
 

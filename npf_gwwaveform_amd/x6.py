@@ -1,5 +1,6 @@
 """x6 programs (``npf_x6_run``, ``csrc/x6_kernel.hip``): whole sides of the model as one launch with every multiply an fp32
-product on the bf16 matrix pipe (three exact bf16 terms per operand, six cross products, fp32 accumulation).
+product on the bf16 matrix pipe (three exact bf16 terms per operand, six cross products, fp32 accumulation; in the bf16 compute mode one bf16 term per
+operand: b16 programs, ``npf_b16_run``, csrc/b16_kernel.hip).
 
 ``target_side`` is the fused target side of an attentive deterministic model (AttnCNP with scaled-dot attention,
 npf/neuralproc/attnnp.py:118-131 + base.py:327-367): x-encoder from the raw frequencies, cross attention over the task's context

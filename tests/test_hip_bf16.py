@@ -188,7 +188,7 @@ def _gate(name, case, params, inp):
 @pytest.mark.parametrize("name", ["g3_attncnp_c2", "g4_attnlnp_c2", "g1_cnp_c1"])
 def test_fused_layer_stores_change_nothing(name, monkeypatch):
     """NPF_F_STORE_IN / NPF_F_STORE_BITS (a STORE_PT in front of a bf16 LINEAR and a STORE_MASK behind a ReLU layer ride
-    inside the layer, DESIGN.md 8.1) move stores, not arithmetic, and PAD_SMALL_K (a <= 32-input layer behind LOAD_ROWS run
+    inside the layer, DESIGN.md 8.2) move stores, not arithmetic, and PAD_SMALL_K (a <= 32-input layer behind LOAD_ROWS run
     as a zero-padded 256-input pipelined layer) only adds exact zeros: outputs, loss and every gradient are BIT-identical
     to the same step with both switched off (NPF_NO_FUSED_STORE, NPF_NO_PAD_SMALL_K)."""
     from npf_gwwaveform_amd import chain as CH

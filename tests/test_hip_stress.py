@@ -47,7 +47,7 @@ def _random_case(rng: random.Random) -> dict:
         case["encoded_path"] = rng.choice(["latent", "both"])
     if kind in ("AttnCNP", "AttnLNP") and r % 32 == 0 and rng.random() < 0.3:
         case["attention"] = rng.choice(["multihead", "transformer"])
-    # the reference's other MLP / merge options (DESIGN.md 3.6)
+    # the reference's other MLP / merge options (DESIGN.md 3.8)
     if rng.random() < 0.25:
         case["is_res"] = True
     if case.get("attention", "scaledot") == "scaledot" and rng.random() < 0.25:

@@ -12,7 +12,7 @@ store of the chain's ends drops out), for four program shapes:
     python tools/bf16_layer_slope.py layers                                       # bare shape, 0..16 layers
 
 VARIANTS may carry extra -D flags for a timing-only build of the library (round 2 used NPF_ABL_* switches that removed the
-MFMAs, the LDS reads, the DMA, the barrier or the whole stage; what they showed is in DESIGN.md section 8.1 -- the switches
+MFMAs, the LDS reads, the DMA, the barrier or the whole stage; what they showed is in DESIGN.md Appendix A -- the switches
 themselves are gone from the kernel).  Round 2, 1M points: bare 0.159 -> 0.126 ms per layer, fwd_train 0.234, bwd_train 0.218.
 """
 import os

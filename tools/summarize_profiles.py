@@ -43,16 +43,19 @@ def _grid(row) -> int:
 # x6 programs: one kernel, four launches per train step (npf_gwwaveform_amd/x6.py).  The two target-side launches -- the ones
 # that hold the scaled-dot attention -- have the larger grid; within a side the launches alternate forward, dgrad.
 X6 = "npf::x6_program_kernel"
+B16 = "npf::b16_program_kernel"  # the same programs in the bf16 compute mode (config 3)
 
 
 class _X6Rows:
     """Names the dispatches of the x6 program kernel by side (grid size) and direction (order of appearance)."""
 
-    def __init__(self):
+    def __init__(self, kernel=X6):
+        self.kernel = kernel
         self.seen = collections.Counter()
         self.ids = {}
 
     def feed(self, rows):
+        X6 = self.kernel
         rows = [r for r in rows if kname(r.get("Kernel_Name", r.get("Name", ""))) == X6]
         if not rows:
             return
@@ -79,15 +82,17 @@ def counters(d):
     if not f:
         return out
     rows = list(csv.DictReader(open(f)))
-    x6 = _X6Rows()
+    progs = [_X6Rows(X6), _X6Rows(B16)]
     # (a dispatch has one row per counter: classify on one counter's rows only)
     first = rows[0]["Counter_Name"] if rows else None
-    x6.feed([r for r in rows if r["Counter_Name"] == first])
+    for x6 in progs:
+        x6.feed([r for r in rows if r["Counter_Name"] == first])
     for row in rows:
         out[kname(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        sub = x6.name(row)
-        if sub:
-            out[sub][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for x6 in progs:
+            sub = x6.name(row)
+            if sub:
+                out[sub][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return out
 
 
@@ -98,12 +103,12 @@ def trace_rows(d):
     if not f:
         return out
     rows = list(csv.DictReader(open(f)))
-    x6 = _X6Rows()
-    x6.feed(rows)
-    for r in rows:
-        sub = x6.name(r)
-        if sub:
-            out[sub].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    for x6 in (_X6Rows(X6), _X6Rows(B16)):
+        x6.feed(rows)
+        for r in rows:
+            sub = x6.name(r)
+            if sub:
+                out[sub].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return out
 
 
@@ -125,7 +130,7 @@ def main():
                 k["avg_ns"] = k["total_ns"] / k["calls"]
     for sub, durs in trace_rows(os.path.join(src, "stats")).items():
         summary["kernels"][sub] = {"calls": len(durs), "total_ns": sum(durs), "avg_ns": sum(durs) / len(durs),
-                                   "row_of": X6}
+                                   "row_of": sub.split(" [")[0]}
     fetch, write, mfma = (counters(os.path.join(src, k)) for k in ("fetch", "write", "mfma"))
     for name in list(summary["kernels"]):
         k = summary["kernels"][name]
