@@ -19,6 +19,7 @@
 // garbage, only the clock counts.  None is defined in the library build.
 //   BP_NO_MFMA no matrix instructions   BP_NO_FRAG no fragment / bias reads from LDS   BP_NO_DMA no slab DMA
 //   BP_NO_STORE no global stores of the ops   BP_NO_BARRIER no slab barriers / counted waits   BP_NO_EPI no block epilogues
+//   BP_STORE_LOCAL the PT16 stores of every workgroup land on the first 64 tiles (the instructions stay, HBM sees few of them)
 
 namespace npf {
 
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   constexpr int LA = Slots - 1;             // slabs in flight ahead
   constexpr int TPW = NPG * NW / 2;         // tiles per workgroup
   static_assert(NB <= 16, "a lane's ReLU bits are one 64-bit word");
-  __shared__ __attribute__((aligned(16))) char smem[Slots * G::SlabB + G::BiasB + KF * 16];
+  __shared__ __attribute__((aligned(16))) char smem[Slots * G::SlabB + G::BiasB + KF * 16 + kXpTableBytes];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
     return (f32x4*)((char*)const_cast<float*>(base + tile_off + (size_t)(b * 512 + 64 * pg)) + lane_b);
   };
   auto pt16 = [&](const float* base, int pg, int st) -> xp_u32x4* {
+#ifdef BP_STORE_LOCAL  // (timing only: every workgroup's PT16 tensors land on the first 64 tiles -- the stores stay, HBM sees few)
+    return (xp_u32x4*)((char*)const_cast<float*>(base) + (tile_off & (size_t)(63 * KF * 32)) * 2 + (size_t)(st * 2048 + 256 * pg) + lane16);
+#endif
     return (xp_u32x4*)((char*)const_cast<float*>(base) + tile_off * 2 + (size_t)(st * 2048 + 256 * pg) + lane16);
   };
 
@@ -126,7 +130,14 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   constexpr int LPR = 64 / G::RPP;  // lanes per row of a piece
   const int l_row = lane / LPR, l_pos = lane % LPR;
   const int n_slabs = a.n_mm * NS;
-  auto mm_base = [&](int j) { return a.mm_img[j] + (size_t)task * a.mm_stride[j]; };
+  // (the op table and the images of the multiplies, from LDS: x6_args.hpp)
+  const unsigned table0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + Slots * G::SlabB + G::BiasB + KF * 16);
+  auto mm_base = [&](int j) -> const char* {
+    typedef const __attribute__((address_space(1))) char* gc_t;
+    const unsigned at = table0 + NPF_X6_MAX_OPS * kXpOpDwords * 4 + (unsigned)j * 8;
+    const unsigned long long img = xp_lds_u64(at), stride = xp_lds_u64(at + NPF_X6_MAX_OPS * 8);
+    return (const char*)(gc_t)(img + (unsigned long long)task * stride);
+  };
   // piece n of this wave's share of the slab whose first image row is ``rows``
   auto dma_piece = [&](const char* img, int rows, char* slot, int n) {
 #ifdef BP_NO_DMA
@@ -148,6 +159,8 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   float* bias_lds = (float*)(smem + Slots * G::SlabB);
   f32x4* out_w_lds = (f32x4*)(smem + Slots * G::SlabB + G::BiasB);
 
+  xp_stage_ops(a, (unsigned*)(smem + Slots * G::SlabB + G::BiasB + KF * 16), tid, NW * 64);
+  __syncthreads();
   if (n_slabs > 0) dma_slab(0, smem);
   if (LA > 1 && n_slabs > 1) dma_slab(1, smem + G::SlabB);
   // every multiply's bias row goes to LDS once, here (read back per 16-row block behind the barriers of the slab loop), and so does
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   const unsigned long long st_first = st_last;
 #endif
   for (int l = 0; l < a.n_ops; ++l) {
-    const npf_x6_op_t& o = a.op[l];
+    const npf_x6_op_t o = xp_lds_op(table0, l);
     const int oflags = o.reserved[0];
     BP_STAMP(0)  // loop back edge, op fields
     // ---------------------------------------------------------------- input side

@@ -47,6 +47,90 @@ __device__ __forceinline__ float xp_max4(float v) {
   return v;
 }
 
+// The program's op table in LDS.  The descriptors are kernel arguments: every `a.op[l].field` is a scalar load whose first touch
+// of a descriptor misses the scalar cache and costs a memory round trip at the top of EVERY op (tools/stamp_probe_b16.py: 2200
+// cycles per op for the fields alone, more for the pointers the input side tests) -- and a scalar load cannot be issued ahead.
+// So the workgroup copies the table to LDS once (vector loads, one round trip; xp_stage_ops) and an op is fetched by broadcast
+// ds_read_b64 + readfirstlane (xp_lds_op), as csrc/chain_kernel.hip does for its bf16 instance.
+constexpr int kXpOpDwords = sizeof(npf_x6_op_t) / 4;
+constexpr int kXpMmDwords = 4 * NPF_X6_MAX_OPS * 2;                           // mm_img, mm_stride, mm_bias, mm_bias_stride
+constexpr int kXpTableBytes = (NPF_X6_MAX_OPS * kXpOpDwords + kXpMmDwords) * 4;
+static_assert(sizeof(npf_x6_op_t) == 168 && kXpOpDwords == 42, "npf_x6_op_t layout");
+
+// (call once per workgroup, then __syncthreads() before the first xp_lds_op)
+__device__ __forceinline__ void xp_stage_ops(const XpArgs& a, unsigned* table, int tid, int n_threads) {
+  for (int t = tid; t < a.n_ops * kXpOpDwords; t += n_threads) table[t] = ((const unsigned*)a.op)[t];
+  unsigned* mm = table + NPF_X6_MAX_OPS * kXpOpDwords;
+  for (int t = tid; t < 2 * NPF_X6_MAX_OPS; t += n_threads) {
+    mm[t] = ((const unsigned*)a.mm_img)[t];
+    mm[2 * NPF_X6_MAX_OPS + t] = ((const unsigned*)a.mm_stride)[t];
+  }
+}
+
+// a 64-bit entry of the table as a wave-uniform value (``byte_addr``: its LDS address)
+__device__ __forceinline__ unsigned long long xp_lds_u64(unsigned byte_addr) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  u32x2_t r;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(byte_addr));
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r[1]) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)r[0]);
+}
+
+__device__ __forceinline__ npf_x6_op_t xp_lds_op(unsigned table_addr, int l) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const unsigned a = table_addr + (unsigned)l * (kXpOpDwords * 4);
+  u32x2_t r[21];
+  asm volatile(
+      "ds_read_b64 %0, %21\n\tds_read_b64 %1, %21 offset:8\n\tds_read_b64 %2, %21 offset:16\n\tds_read_b64 %3, %21 offset:24\n\t"
+      "ds_read_b64 %4, %21 offset:32\n\tds_read_b64 %5, %21 offset:40\n\tds_read_b64 %6, %21 offset:48\n\tds_read_b64 %7, %21 offset:56\n\t"
+      "ds_read_b64 %8, %21 offset:64\n\tds_read_b64 %9, %21 offset:72\n\tds_read_b64 %10, %21 offset:80\n\tds_read_b64 %11, %21 offset:88\n\t"
+      "ds_read_b64 %12, %21 offset:96\n\tds_read_b64 %13, %21 offset:104\n\tds_read_b64 %14, %21 offset:112\n\tds_read_b64 %15, %21 offset:120\n\t"
+      "ds_read_b64 %16, %21 offset:128\n\tds_read_b64 %17, %21 offset:136\n\tds_read_b64 %18, %21 offset:144\n\tds_read_b64 %19, %21 offset:152\n\t"
+      "ds_read_b64 %20, %21 offset:160\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+        "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15]), "=&v"(r[16]), "=&v"(r[17]),
+        "=&v"(r[18]), "=&v"(r[19]), "=&v"(r[20])
+      : "v"(a));
+  unsigned long long q[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k)
+    q[k] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r[k][1]) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)r[k][0]);
+  // (a generic pointer rebuilt from integers makes every access through it a flat_load / flat_store -- slower to issue, counted
+  // on vmcnt AND lgkmcnt; built as global pointers, the accesses stay global_*)
+  typedef const __attribute__((address_space(1))) void* gc_t;
+  typedef __attribute__((address_space(1))) void* gw_t;
+  static_assert(offsetof(npf_x6_op_t, w_img) == 80 && offsetof(npf_x6_op_t, store_bits) == 128 &&
+                offsetof(npf_x6_op_t, in_n) == 136, "npf_x6_op_t layout");
+  npf_x6_op_t o;
+  o.in_pt = (const float*)(gc_t)q[0];
+  o.in_rows = (const float*)(gc_t)q[1];
+  o.in_w = (const float*)(gc_t)q[2];
+  o.in_b = (const float*)(gc_t)q[3];
+  o.pre_add = (const float*)(gc_t)q[4];
+  o.mask = (const float*)(gc_t)q[5];
+  o.mask_bits = (const unsigned long long*)(gc_t)q[6];
+  o.sbwd_p = (const float*)(gc_t)q[7];
+  o.store_in = (float*)(gw_t)q[8];
+  o.store_in_bits = (unsigned long long*)(gw_t)q[9];
+  o.w_img = (const void*)(gc_t)q[10];
+  o.w_task_stride = (int64_t)q[11];
+  o.bias = (const float*)(gc_t)q[12];
+  o.bias_task_stride = (int64_t)q[13];
+  o.addend = (const float*)(gc_t)q[14];
+  o.store_out = (float*)(gw_t)q[15];
+  o.store_bits = (unsigned long long*)(gw_t)q[16];
+  o.in_n = (int32_t)(unsigned)q[17];
+  o.in_relu = (int32_t)(q[17] >> 32);
+  o.relu = (int32_t)(unsigned)q[18];
+  o.softmax_n = (int32_t)(q[18] >> 32);
+  o.softmax_scale = __uint_as_float((unsigned)q[19]);
+  o.sbwd_scale = __uint_as_float((unsigned)(q[19] >> 32));
+  o.reserved[0] = (int32_t)(unsigned)q[20];
+  o.reserved[1] = (int32_t)(q[20] >> 32);
+  return o;
+}
+
 // Validates a program and fills ``a`` (everything but the grid geometry: wgs_per_task, xcd_remap).  ``flag_mask``: the op flags
 // (reserved[0]) this interpreter knows; ``bits_max_width``: the widest program that may carry ReLU-bit / softmax operands.
 inline int xp_fill_args(const npf_x6_op_t* ops, int32_t n_ops, const float* out_w, const float* out_b, float* out_rows,
