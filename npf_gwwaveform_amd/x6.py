@@ -407,7 +407,8 @@ class _TargetSideFn(torch.autograd.Function):
         # weight gradient multiplies and its bias gradient sums -- except the merge layer's, which is also the fp32 gradient of x1)
         for i in range(n_dec - 1, -1, -1):
             j = n_x + i
-            is_merge = i == n_mrz + n_res - 1
+            # (... and the latent merge's: the per-task bias gradient is the fp32 sum of it over the task's points)
+            is_merge = i == n_mrz + n_res - 1 or (n_mrz and i == 0)
             dz[j] = pt() if is_merge else pb()
             o = dict(mask_bits=d_bits[i], store_in=dz[j], store_in_f32=is_merge, img=bw[j], w_ref=wref(j))
             if i == n_dec - 1:
@@ -486,7 +487,7 @@ def target_side_usable(model, C: int, T: int, latent_merge: bool = False) -> boo
     wide layer 256 -> 256, no residual / dropout; ``latent_merge``: with AttnLNP's merge_r_z between attention and decoder."""
     from .architectures import MLP, DotAttender
 
-    if not _mode_ok() or (latent_merge and CH.COMPUTE_DTYPE != "fp32"):
+    if not _mode_ok():
         return False
     WIDTH = _width_of(model)
     if not WIDTH:
