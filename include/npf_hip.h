@@ -427,7 +427,7 @@ int npf_x6_task_images(const float *src, int32_t n_tasks, int32_t pts, int32_t w
  *                            F -> 4 layer rounds its input itself;
  *   mask (PT32), row-major operands: not available.
  * Whole tiles only (pts_per_task = 32 tiles_per_task).  variant: 0 = the library's choice (1), 1 = eight waves per workgroup on one
- * ring of three slabs (one workgroup per CU), 2 = four waves and a ring of two slabs (two workgroups per CU). */
+ * ring of three 64-row slabs (one workgroup per CU), 2 = four waves and three 32-row slabs (two workgroups per CU). */
 int npf_b16_run(const npf_x6_op_t *ops, int32_t n_ops, const float *out_w, const float *out_b, float *out_rows, int32_t n_tasks,
                 int32_t tiles_per_task, int32_t per_task, int32_t width, int32_t variant, void *stream);
 /* npf_x6_task_images with the rounded value alone: row_img / tr_img [n_tasks][F][F] bf16. */

@@ -51,7 +51,7 @@ struct BpGeom {
   static constexpr int NPW = 16 * RB / RPP / NW;  // pieces per wave and slab
   static constexpr int BiasB = NPF_X6_MAX_OPS * KF * 4;  // the bias rows of every multiply of the program
   static_assert(NB % RB == 0 && RB % 2 == 0 && NPW >= 1 && (16 * RB / RPP) % NW == 0, "slab geometry");
-  static_assert(NS >= 2 && (SLOTS == 2 || SLOTS == 3) && (NW_ == 4 || NW_ == 8), "ring geometry");
+  static_assert(NS >= 2 && SLOTS >= 2 && SLOTS <= 4 && (NW_ == 4 || NW_ == 8), "ring geometry");
 };
 
 // round to bf16 and back (a value as the next multiply sees it)
@@ -72,9 +72,9 @@ __device__ __forceinline__ void bp_unpack(const xp_u32x4& t, f32x4& lo, f32x4& h
   hi[3] = __uint_as_float(t[3] & 0xffff0000u);
 }
 
-// NPG = 16-point groups per wave (1 in every instance the library launches: a wave owns half a tile; 2 = a whole tile).  NW_ = waves per workgroup sharing one slab ring, SLOTS
-// its slots: <.., 8, 3> one workgroup per CU; <.., 4, 2> two workgroups per CU, out of step with each other -- one multiplies
-// while the other sits in an op's input side or at a barrier.
+// NPG = 16-point groups per wave (1 in every instance the library launches: a wave owns half a tile; 2 = a whole tile).  NW_ =
+// waves per workgroup sharing one slab ring, SLOTS its slots: <.., RB = 4, 8, 3> one workgroup per CU; <.., RB = 2, 4, 3> two
+// workgroups per CU, out of step with each other.
 template <int KF, int NPG, int RB, int NW_, int SLOTS>
 __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_program_kernel(const XpArgs a) {
   using G = BpGeom<KF, RB, NW_, SLOTS>;
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   __syncthreads();
   if (n_slabs > 0) dma_slab(0, smem);
   if (LA > 1 && n_slabs > 1) dma_slab(1, smem + G::SlabB);
+  if (LA > 2 && n_slabs > 2) dma_slab(2, smem + 2 * G::SlabB);
   // every multiply's bias row goes to LDS once, here (read back per 16-row block behind the barriers of the slab loop), and so does
   // the matrix of the F -> 4 layer behind the program: no op starts by waiting for a global load.  All loads first, then the stores.
   {
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
       else
 #endif
       if (s == 0 && has_add && NB * NPG <= 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NB * NPG) : "memory");
-      else if (LA > 1 && S + 1 < n_slabs) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((LA - 1) * NPW) : "memory");
+      else if (LA > 2 && S + 2 < n_slabs) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((LA - 1) * NPW) : "memory");
+      else if (LA > 1 && S + 1 < n_slabs) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW) : "memory");
 #ifdef BP_NO_BARRIER
       else if (false) {}
 #endif
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
         switch (NR - 1 - j < W - 1 ? NR - 1 - j : W - 1) {
 #define BP_WAIT(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f)); break
           BP_WAIT(0); BP_WAIT(1); BP_WAIT(2); BP_WAIT(3); BP_WAIT(4); BP_WAIT(5); BP_WAIT(6); BP_WAIT(7); BP_WAIT(8);
+          BP_WAIT(9); BP_WAIT(10); BP_WAIT(11); BP_WAIT(12); BP_WAIT(13); BP_WAIT(14);
 #undef BP_WAIT
         }
         if (q == 0) {
@@ -548,10 +551,11 @@ extern "C" int npf_b16_run(const npf_x6_op_t* ops, int32_t n_ops, const float* o
   if (rc != NPF_OK) return rc;
   for (int l = 0; l < n_ops; ++l)
     if (ops[l].mask != nullptr) return NPF_EINVAL;  // (ReLU masks are bits here)
-  // 1 = eight waves of 16 points share a ring of three slabs, one workgroup per CU (the library's choice); 2 = four waves of 16
-  // points and a ring of two slabs, two workgroups per CU.  (Measured on config 3, target side forward: 2.60 ms (1), 2.97 (2);
-  // 32 points per wave -- every weight fragment feeding two matrix instructions -- 4.17 at two waves per SIMD (256 registers do
-  // not hold it: spills in the slab loop) and 3.35 at one wave per SIMD with 404 registers)
+  // 1 = eight waves of 16 points share a ring of three 64-row slabs, one workgroup per CU (the library's choice); 2 = four waves
+  // of 16 points and a ring of three 32-row slabs, two workgroups per CU, out of step with each other.  (Measured on config 3,
+  // target side forward: 2.64 ms (1), 2.81 (2); 32 points per wave -- every weight fragment feeding two matrix instructions --
+  // 4.17 at two waves per SIMD (256 registers do not hold it: spills in the slab loop) and 3.35 at one wave per SIMD with 404
+  // registers; a ring of four slabs, or 3 / 5 / 13 LDS reads ahead instead of 9: no change.  DESIGN.md 8.1.)
   const int var = variant == 0 ? 1 : variant;
   const int tpw = var == 2 ? 2 : 4;
   a.wgs_per_task = per_task ? (tiles_per_task + tpw - 1) / tpw : 0;
@@ -560,10 +564,10 @@ extern "C" int npf_b16_run(const npf_x6_op_t* ops, int32_t n_ops, const float* o
   const dim3 grid(n_wg);
   hipStream_t st = (hipStream_t)stream;
   if (width == 256) {
-    if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<256, 1, 4, 4, 2>), grid, dim3(256), 0, st, a);
+    if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<256, 1, 2, 4, 3>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((npf::b16_program_kernel<256, 1, 4, 8, 3>), grid, dim3(512), 0, st, a);
   } else {
-    if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<128, 1, 4, 4, 2>), grid, dim3(256), 0, st, a);
+    if (var == 2) hipLaunchKernelGGL((npf::b16_program_kernel<128, 1, 2, 4, 3>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((npf::b16_program_kernel<128, 1, 4, 8, 3>), grid, dim3(512), 0, st, a);
   }
   NPF_CHECK_LAUNCH();

@@ -39,7 +39,7 @@ def test_b16_task_images_are_the_rounded_values(pts, width):
     assert torch.equal(_unpermute(tr.cpu()).float(), r16(want.transpose(1, 2)))
 
 
-@pytest.mark.parametrize("variant", [1, 2], ids=["8_waves_3_slabs", "4_waves_2_slabs"])
+@pytest.mark.parametrize("variant", [1, 2], ids=["8_waves_64_row_slabs", "4_waves_32_row_slabs"])
 @pytest.mark.parametrize("B,C,T,L,dx,dy,r", [(2, 256, 64, 4, 1, 2, 256), (3, 200, 96, 2, 2, 1, 256), (1, 129, 33, 1, 1, 2, 256),
                                              (9, 250, 288, 2, 1, 2, 256), (3, 128, 64, 2, 1, 2, 128), (4, 5, 70, 1, 2, 1, 128)])
 def test_b16_fused_sides_teacher_forced(B, C, T, L, dx, dy, r, variant, monkeypatch, bf16_mode):
