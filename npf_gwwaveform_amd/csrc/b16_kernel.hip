@@ -156,6 +156,9 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lane_row = (unsigned)(p * G::RowB);
+  unsigned fx[KS];  // this lane's chunk of row p per k-step, from the ring's first byte
+#pragma unroll
+  for (int st = 0; st < KS; ++st) fx[st] = lds0 + lane_row + (unsigned)((((4 * st + g) ^ p)) << 4);
   float* bias_lds = (float*)(smem + Slots * G::SlabB);
   f32x4* out_w_lds = (f32x4*)(smem + Slots * G::SlabB + G::BiasB);
 
@@ -373,19 +376,38 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
       // LDS reads return in order, so read j has landed once at most min(W - 1, NR - 1 - j) later ones are outstanding.
       constexpr int W = 9, NR = RB * (KS + 1);
       xp_u32x4 ring[W + 1];
+      // (addresses: one register per k-step for the slab -- the lane's swizzled chunk of row p -- and the 16-row block / the bias row as
+      // the instruction's immediate offset: one vector add per k-step and slab instead of one per read)
+      unsigned fb[KS];
+#pragma unroll
+      for (int st = 0; st < KS; ++st) fb[st] = fx[st] + (unsigned)(slot * G::SlabB);
       auto rd = [&](int j) {
         const int rb = j / (KS + 1), q = j % (KS + 1);
-        const unsigned addr = q == 0 ? bias_l + 64 * (s * RB + rb) : sl + rb * 16 * G::RowB + (((4 * (q - 1) + g) ^ p) << 4);
+        xp_u32x4& dst = ring[j % (W + 1)];
 #ifdef BP_NO_FRAG
-        asm volatile("" : "=v"(ring[j % (W + 1)]) : "v"(addr));
+        asm volatile("" : "=v"(dst) : "v"(fb[0]));
 #else
-        asm volatile("ds_read_b128 %0, %1" : "=v"(ring[j % (W + 1)]) : "v"(addr));
+#define BP_RD(N, BASE, OFF) case N: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(BASE), "n"(OFF)); break
+        if (q == 0) {
+          switch (s * RB + rb) {
+            BP_RD(0, bias_l, 0); BP_RD(1, bias_l, 64); BP_RD(2, bias_l, 128); BP_RD(3, bias_l, 192); BP_RD(4, bias_l, 256);
+            BP_RD(5, bias_l, 320); BP_RD(6, bias_l, 384); BP_RD(7, bias_l, 448); BP_RD(8, bias_l, 512); BP_RD(9, bias_l, 576);
+            BP_RD(10, bias_l, 640); BP_RD(11, bias_l, 704); BP_RD(12, bias_l, 768); BP_RD(13, bias_l, 832); BP_RD(14, bias_l, 896);
+            BP_RD(15, bias_l, 960);
+          }
+        } else {
+          switch (rb) {
+            BP_RD(0, fb[q - 1], 0); BP_RD(1, fb[q - 1], 16 * G::RowB); BP_RD(2, fb[q - 1], 32 * G::RowB); BP_RD(3, fb[q - 1], 48 * G::RowB);
+          }
+        }
+#undef BP_RD
 #endif
       };
 #pragma unroll
       for (int j = 0; j < W; ++j) rd(j);
-      // two accumulators per point group (even / odd k-steps): no back-to-back dependent matrix instructions
-      constexpr int NA = 2;
+      // one accumulator per point group (a second one for the odd k-steps -- no back-to-back dependent matrix instructions --
+      // measured 1 % slower: its sum is two more vector instructions per block, and the sibling wave fills the gaps)
+      constexpr int NA = 1;
       f32x4 acc[NPG][NA];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -423,10 +445,17 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
 #pragma unroll
           for (int pg = 0; pg < NPG; ++pg) {
             f32x4 r = NA == 2 ? acc[pg][0] + acc[pg][NA - 1] : acc[pg][0];
-            if (has_add) r += cur[pg][sb];
-            if (relu) {
+            if (has_add) {  // (the empty asm keeps this a wave-uniform branch: as a select it costs every op four instructions per block)
+              asm volatile("" ::: "memory");
+              r += cur[pg][sb];
+            }
+            if (relu) {  // (v_max_f32 as is: fmaxf would canonicalise its operand first, a second instruction per value)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+              for (int e = 0; e < 4; ++e) {
+                float x = r[e];  // (through a scalar: see the note on ext_vector elements in csrc/x6_kernel.hip)
+                asm("v_max_f32 %0, 0, %0" : "+v"(x));
+                r[e] = x;
+              }
             }
             cur[pg][sb] = r;  // (block sb of the input is dead: it is in tb)
 #pragma unroll
