@@ -360,7 +360,6 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && NPG == 1) ? 2 : 1) void b16_
       BP_STAMP(3)  // counted wait + barrier
       const bool more = S + LA < n_slabs;
       char* const nslot = smem + ((slot + LA) % Slots) * G::SlabB;
-      const unsigned sl = lds0 + slot * G::SlabB + lane_row;
       // HERE none of this wave's LDS reads is outstanding (csrc/x6_kernel.hip: vector-memory instructions issued while fragment
       // reads were in flight gave sporadic wrong results); from here to the end of the slab the wave keeps LDS reads in flight.
       // So the previous slab's output blocks are stored now -- a whole slab ahead of the barrier that waits for them -- and then

@@ -396,10 +396,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KF * NPG <= 256) ? 2 : 1) void
 #pragma unroll
       for (int pg = 0; pg < NPG; ++pg) {
         f32x4 r = acc[pg] + sm[pg];
-        if (has_add) r += cur[pg][s];
-        if (relu) {
+        if (has_add) {  // (the empty asm keeps this a wave-uniform branch: as a select it costs every op four instructions per slab)
+          asm volatile("" ::: "memory");
+          r += cur[pg][s];
+        }
+        if (relu) {  // (v_max_f32 as is: fmaxf canonicalises its operand first, a second instruction per value)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+          for (int e = 0; e < 4; ++e) {
+            float x = r[e];
+            asm("v_max_f32 %0, 0, %0" : "+v"(x));
+            r[e] = x;
+          }
         }
         cur[pg][s] = r;  // (block s of the input is dead: its terms are in tb)
         if (out != nullptr) __builtin_nontemporal_store(r, pt32(out, pg, s));
@@ -592,10 +599,17 @@ __global__ __launch_bounds__(512) void x6_wide512_kernel(const XpArgs a) {
         f32x4 x;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(xb0 + (s & 1) * 4096) : "memory");
         f32x4 r = hold + x;
-        if (has_add) r += cur[s & 15];
+        if (has_add) {  // (a wave-uniform branch, see x6_program_kernel)
+          asm volatile("" ::: "memory");
+          r += cur[s & 15];
+        }
         if (relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+          for (int e = 0; e < 4; ++e) {
+            float v = r[e];
+            asm("v_max_f32 %0, 0, %0" : "+v"(v));
+            r[e] = v;
+          }
         }
         cur[s & 15] = r;
         if (out != nullptr) __builtin_nontemporal_store(r, pt32(out, s & 15));
