@@ -117,6 +117,8 @@ SIGNATURES = {
     "npf_x6_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "npf_b16_run": (C.c_int, [C.POINTER(NpfX6Op), _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "npf_b16_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
+    "npf_mha_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "npf_mha_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     "npf_version": (C.c_int, []),
 }
 

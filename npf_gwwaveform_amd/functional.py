@@ -3,6 +3,7 @@ points of a task, and the Gaussian head.  Every function launches HIP kernels th
 C ABI (``_lib``); none has a CPU path."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -218,3 +219,71 @@ def split_heads(x_pt: torch.Tensor, n_tasks: int, pts: int, F: int, n_heads: int
 def merge_heads(x_pt: torch.Tensor, n_tasks: int, pts: int, F: int, n_heads: int) -> torch.Tensor:
     """Inverse of :func:`split_heads`."""
     return _HeadsFn.apply(x_pt, n_tasks, pts, F, n_heads, False)
+
+
+MHA_HEAD = 16      # head size of the fused multihead attention kernel (csrc/mha_kernel.hip)
+MHA_MAX_KEYS = 256
+MHA_ENABLED = os.environ.get("NPF_NO_MHA", "0") != "1"  # NPF_NO_MHA=1: heads as extra tasks on the chain kernel (round 2)
+
+
+class _MhaFn(torch.autograd.Function):
+    """out[b, q, 16 h + :] = softmax_k(Q_h K_h^T / 4) V_h on the PT32 tensors of the K / Q / V projections (``npf_mha_fwd`` /
+    ``npf_mha_bwd``; MultiheadAttender.forward, npf/architectures/attention.py:505-527 with DotAttender :204-220 per head)."""
+
+    @staticmethod
+    def forward(ctx, q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads):
+        from . import chain as CH
+
+        F = n_heads * MHA_HEAD
+        q_pt, k_pt, v_pt = q_pt.contiguous(), k_pt.contiguous(), v_pt.contiguous()
+        train = any(ctx.needs_input_grad[:3])
+        # (zeros: the features of a padded tile beyond F and the points beyond n_queries are not written by the kernel)
+        out = torch.zeros(CH.pt_shape(n_tasks, n_queries, F), dtype=torch.float32, device=q_pt.device)
+        lse = torch.empty((n_tasks, n_heads, n_queries), dtype=torch.float32, device=q_pt.device) if train else None
+        if CH.PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().npf_mha_fwd(L.ptr(q_pt), L.ptr(k_pt), L.ptr(v_pt), n_tasks, n_heads, n_keys, n_queries, F, L.ptr(out),
+                                     L.ptr(lse) if lse is not None else None, L.stream_ptr()), "npf_mha_fwd")
+        if CH.PROFILE is not None:
+            ev1.record()
+            CH.PROFILE.append(("mha_fwd_kernel", 4 * n_tasks * n_queries * n_keys * F, ev0, ev1,
+                               4 * F * n_tasks * (2 * n_queries + 2 * n_keys), "multihead attention"))
+        ctx.geom = (n_tasks, n_keys, n_queries, n_heads, F)
+        if train:
+            ctx.save_for_backward(q_pt, k_pt, v_pt, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import chain as CH
+
+        n_tasks, n_keys, n_queries, n_heads, F = ctx.geom
+        q_pt, k_pt, v_pt, out, lse = ctx.saved_tensors
+        g = g.contiguous()
+        dq, dk, dv = torch.zeros_like(q_pt), torch.zeros_like(k_pt), torch.zeros_like(v_pt)
+        if CH.PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().npf_mha_bwd(L.ptr(q_pt), L.ptr(k_pt), L.ptr(v_pt), L.ptr(out), L.ptr(g), L.ptr(lse), n_tasks, n_heads,
+                                     n_keys, n_queries, F, L.ptr(dq), L.ptr(dk), L.ptr(dv), L.stream_ptr()), "npf_mha_bwd")
+        if CH.PROFILE is not None:
+            ev1.record()
+            CH.PROFILE.append(("mha_bwd_kernel", 14 * n_tasks * n_queries * n_keys * F, ev0, ev1,
+                               4 * F * n_tasks * (4 * n_queries + 4 * n_keys), "multihead attention backward"))
+        return dq, dk, dv, None, None, None, None
+
+
+def mha_usable(kq_head: int, v_head: int, n_keys: int) -> bool:
+    """Does the fused multihead attention kernel take this: fp32 mode, 16-feature heads, at most 256 keys."""
+    from . import chain as CH
+
+    return (MHA_ENABLED and CH.COMPUTE_DTYPE == "fp32" and kq_head == MHA_HEAD and v_head == MHA_HEAD
+            and 0 < n_keys <= MHA_MAX_KEYS)
+
+
+def mha(q_pt: torch.Tensor, k_pt: torch.Tensor, v_pt: torch.Tensor, n_tasks: int, n_keys: int, n_queries: int,
+        n_heads: int) -> torch.Tensor:
+    """PT32 [n_tasks, n_queries, 16 n_heads]: per-head scaled-dot attention of the projected queries over the projected keys /
+    values (``mha_usable``), no split / merge of heads in memory."""
+    return _MhaFn.apply(q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads)

@@ -1,0 +1,64 @@
+"""GPU parity test of the fused multihead attention kernel (csrc/mha_kernel.hip, ``npf_mha_fwd`` / ``npf_mha_bwd``) through the C
+ABI: per-head scaled-dot attention with 16-feature heads (MultiheadAttender.forward between the projections and the concatenation,
+npf/architectures/attention.py:505-527; DotAttender :204-220 per head with the head size in the scale) against a float64
+evaluation -- fp32 arithmetic, so the fp32 gates of SURVEY.md 8c: 1e-5 of max|ref| on the output, 1e-4 on gradients.  The model
+level (multihead / transformer goldens G8 / G9 / G11, the sweep) runs on this kernel too whenever the heads are 16 wide."""
+import math
+
+import pytest
+import torch
+
+from test_hip_x6 import DEV, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(Q, K, V, H):
+    B, T, F = Q.shape
+    d = F // H
+    heads = lambda x: x.view(B, -1, H, d).permute(0, 2, 1, 3)  # noqa: E731
+    S = heads(Q) @ heads(K).transpose(-1, -2) / math.sqrt(d)
+    return (S.softmax(-1) @ heads(V)).permute(0, 2, 1, 3).reshape(B, T, F)
+
+
+@pytest.mark.parametrize("B,C,T,H", [(3, 128, 256, 8), (2, 37, 70, 2), (2, 200, 33, 8), (1, 256, 100, 4), (2, 5, 1, 1), (4, 50, 128, 8),
+                                     (2, 64, 257, 3)])
+def test_mha_matches_float64(B, C, T, H):
+    from npf_gwwaveform_amd import functional as FN
+
+    F = 16 * H
+    assert FN.mha_usable(16, 16, C)
+    g = torch.Generator().manual_seed(B * 1000 + C + T)
+    Q, K, V = (torch.randn(B, n, F, generator=g) * s for n, s in ((T, 1.5), (C, 1.5), (C, 1.0)))
+    w = torch.randn(B, T, F, generator=g)
+    Qd, Kd, Vd = (x.to(DEV).requires_grad_(True) for x in (Q, K, V))
+    out = FN.unpack_pt(FN.mha(FN.pack_pt(Qd), FN.pack_pt(Kd), FN.pack_pt(Vd), B, C, T, H), T, F)
+    (out * w.to(DEV)).sum().backward()
+    Qr, Kr, Vr = (x.double().requires_grad_(True) for x in (Q, K, V))
+    ref = _ref(Qr, Kr, Vr, H)
+    (ref * w.double()).sum().backward()
+    assert_close(out, ref, tol=1e-5, what="attention output")
+    assert_close(Qd.grad, Qr.grad, tol=1e-4, what="dQ")
+    assert_close(Kd.grad, Kr.grad, tol=1e-4, what="dK")
+    assert_close(Vd.grad, Vr.grad, tol=1e-4, what="dV")
+
+
+def test_mha_inference_equals_training_forward():
+    from npf_gwwaveform_amd import functional as FN
+
+    g = torch.Generator().manual_seed(0)
+    Q, K, V = (torch.randn(2, n, 128, generator=g).to(DEV) for n in (96, 50, 50))
+    with torch.no_grad():
+        a = FN.mha(FN.pack_pt(Q), FN.pack_pt(K), FN.pack_pt(V), 2, 50, 96, 8)
+    b = FN.mha(FN.pack_pt(Q.requires_grad_(True)), FN.pack_pt(K), FN.pack_pt(V), 2, 50, 96, 8)
+    assert torch.equal(a, b.detach())
+
+
+def test_mha_rejects_other_head_sizes_and_too_many_keys():
+    from npf_gwwaveform_amd import _lib as L
+    from npf_gwwaveform_amd import chain as CH
+
+    x = CH.pt_empty(1, 32, 128, DEV)
+    lib = L.load()
+    assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 4, 32, 32, 128, L.ptr(x), None, None) == -1   # 128 != 16 * 4
+    assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 8, 257, 32, 128, L.ptr(x), None, None) == -1  # keys > 256
