@@ -532,6 +532,12 @@ class AttnCNP(NeuralProcessFamily):
             from . import x6
 
             return x6.target_side(self, self._X_trgt_raw, Xc_pt, R)
+        if C > 0 and not isinstance(self.attender, DotAttender):
+            from . import x6
+
+            if x6.decoder_side_usable(self, T):
+                # learned projections (multihead / transformer attention): its own launches, then the decoder as one x6 program
+                return x6.decoder_side(self, self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T), Xt_pt.t, T)
         ch = Chain(B, T, Xt_pt.t.device, wg_per_task=True)
         if C == 0:
             ch.input_pt(torch.zeros(pt_shape(B, T, self.r_dim), device=Xt_pt.t.device), self.r_dim)

@@ -467,6 +467,138 @@ class _TargetSideFn(torch.autograd.Function):
         return (None, dK, dV, None, None, None, d_zb, *grads)
 
 
+class _DecoderSideFn(torch.autograd.Function):
+    """rows [B, T, n_out] = decoder(x1, R) = flat(relu(x1 + resizer(R))) + output layer (MergeFlatInputs.forward, encoders.py:175-183,
+    as ``NeuralProcessFamily.decode`` calls it, base.py:327-367) from PT32 tensors: ONE launch forward, ONE for its dgrad, then the
+    weight-gradient jobs -- the decoder half of ``_TargetSideFn`` for models whose attention is not the fused scaled-dot one
+    (multihead / transformer attention, more than 256 keys).  ``spec`` = (n_res, n_flat): F -> F layers of the resizer, of the flat
+    MLP in front of its output layer; params = W, b pairs: resizer, flat, output layer."""
+
+    @staticmethod
+    def forward(ctx, R_pt, X1_pt, T, spec, *params):
+        n_res, n_flat = spec
+        B, tiles = R_pt.shape[0], R_pt.shape[1]
+        dev = R_pt.device
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        W_out, b_out = Ws[-1], bs[-1]
+        n_out = W_out.shape[0]
+        mid_W, mid_b = Ws[:-1], bs[:-1]
+        F = mid_W[0].shape[0]
+        n_mid = n_res + n_flat
+        train = any(ctx.needs_input_grad)
+        imgs = _weight_images(mid_W, (1, 2) if train else (1,), F)
+        fw = imgs[0]
+        R_pt, X1_pt = R_pt.contiguous(), X1_pt.contiguous()
+        pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F)
+        acts, bits = [], []
+        for i in range(n_mid):
+            o = dict(img=fw[i], w_ref=("shared", mid_W[i]), bias=mid_b[i].detach() if mid_b[i] is not None else None, relu=True)
+            if i == 0:
+                o["in_pt"] = R_pt.detach()
+            if i == n_res - 1:
+                o["addend"] = X1_pt.detach()
+            if train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                acts.append(o["store_out"])
+                bits.append(o["store_bits"])
+            prog.op(**o)
+        rows = torch.empty((B, tiles * 32, 4), dtype=torch.float32, device=dev)
+        Wo, bo = _pad_out(W_out, b_out)
+        prog.tail = (Wo, bo, rows)
+        prog.tag = "decoder forward (resizer, merge, flat MLP, output layer)"
+        prog.launch()
+        ctx.geom = (B, T, tiles, n_out, F)
+        ctx.spec = spec
+        ctx.has_b = [b is not None for b in bs]
+        ctx.set_materialize_grads(False)
+        ctx.trace_ref = [W.detach() for W in mid_W] if CH.TRACE is not None else None
+        if train:
+            ctx.save_for_backward(R_pt.detach(), *acts, *bits, *imgs[1], Wo)
+        return rows[:, :T, :n_out]
+
+    @staticmethod
+    def backward(ctx, g):
+        n_res, n_flat = ctx.spec
+        n_mid = n_res + n_flat
+        if g is None:
+            return (None,) * (4 + 2 * (n_mid + 1))
+        B, T, tiles, n_out, F = ctx.geom
+        sv = list(ctx.saved_tensors)
+        R_pt, acts, bits, bw, Wo = sv[0], sv[1:1 + n_mid], sv[1 + n_mid:1 + 2 * n_mid], sv[1 + 2 * n_mid:1 + 3 * n_mid], sv[-1]
+        dev = g.device
+        g4 = torch.zeros((B, tiles * 32, 4), dtype=torch.float32, device=dev)  # (padding points and outputs: zero gradient)
+        g4[:, :T, :n_out] = g
+        pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
+        tr = ctx.trace_ref
+        prog = Program(B, tiles, per_task=False, width=F)
+        dz = [None] * n_mid
+        dR = pt() if ctx.needs_input_grad[0] else None
+        for i in range(n_mid - 1, -1, -1):
+            dz[i] = pt()
+            o = dict(mask_bits=bits[i], store_in=dz[i], img=bw[i], w_ref=("shared", tr[i].t()) if tr is not None else None)
+            if i == n_mid - 1:
+                o.update(in_rows=g4, in_w=Wo)  # the dgrad of the output layer in the prologue
+            if i == 0 and dR is not None:
+                o["store_out"] = dR
+            prog.op(**o)
+        prog.tag = "decoder dgrad"
+        prog.launch()
+        jobs, grads = [], []
+        ins = [R_pt, *acts[:-1]]
+        for j in range(n_mid):
+            dW = torch.empty((F, F), dtype=torch.float32, device=dev)
+            db = torch.empty((F,), dtype=torch.float32, device=dev) if ctx.has_b[j] else None
+            jobs.append(dict(dZ=dz[j], A=ins[j], N=F, K=F, dW=dW, db=db))
+            grads += [dW, db]
+        dz_out = torch.zeros(CH.pt_shape(B, tiles * 32, 4), dtype=torch.float32, device=dev)
+        dz_out[:, :, 0] = g4.view(B, tiles, 32, 4)
+        dWo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
+        dbo = torch.empty((n_out,), dtype=torch.float32, device=dev) if ctx.has_b[-1] else None
+        jobs.append(dict(dZ=dz_out, A=acts[-1], N=n_out, K=F, dW=dWo, db=dbo))
+        grads += [dWo, dbo]
+        CH.run_wgrad(jobs, B, tiles * 32, dev, tag="decoder weight gradients")
+        if CH.TRACE is not None:
+            CH.TRACE.append(("wgrad", jobs, B, tiles * 32, False))
+        dX1 = dz[n_res - 1] if ctx.needs_input_grad[1] else None  # (the merge adds x1 in front of its ReLU: its dZ is x1's gradient)
+        return (dR, dX1, None, None, *grads)
+
+
+def decoder_side_usable(model, T: int) -> bool:
+    """Does ``decoder_side`` cover this model: fp32 mode, a sum-merge decoder whose layers are all F x F with F = 128 (the
+    256-wide ones already run as one launch on ``mlp_x6``), an output layer of <= 4 features, no residual / dropout."""
+    from .architectures import MLP, MergeFlatInputs
+
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or T <= 0:
+        return False
+    dec = getattr(model, "decoder", None)
+    F = getattr(model, "r_dim", 0)
+    if F != 128 or getattr(model, "x_transf_dim", F) != F or not isinstance(dec, MergeFlatInputs):
+        return False
+    if not (dec.is_sum_merge and isinstance(dec.flat_module, MLP)):
+        return False
+    fm, rs = dec.flat_module, dec.resizer
+    for m in (fm, rs):
+        if m.is_res or (m.dropout_p > 0 and m.training):
+            return False
+    if not (_square(rs.layers(), F) and _square([fm.to_hidden, *fm.linears], F) and fm.out.in_features == F
+            and fm.out.out_features <= 4):
+        return False
+    return len(rs.layers()) + len(fm.linears) + 1 <= L.NPF_X6_MAX_OPS
+
+
+def decoder_side(model, R_pt: torch.Tensor, X1_pt: torch.Tensor, T: int) -> torch.Tensor:
+    """The decoder's sufficient statistics [B, T, 2 dy] from the target representations and the encoded targets (PT32 tensors
+    [B, tiles, F/4, 32, 4]; ``decoder_side_usable``)."""
+    dec = model.decoder
+    fm, rs = dec.flat_module, dec.resizer
+    lins = [*rs.layers(), fm.to_hidden, *fm.linears, fm.out]
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    return _DecoderSideFn.apply(R_pt, X1_pt, T, (len(rs.layers()), len(fm.linears) + 1), *params)
+
+
 def _width_of(model) -> int:
     """The feature width F of the model's wide layers if the x6 programs have an instance for it (128, 256), else 0."""
     F = getattr(model, "r_dim", 0)

@@ -242,3 +242,43 @@ def test_decode_rows_from_row_major_inputs_matches_float64(F, n, T, L, dy, varia
 
     ref = mlp(torch.relu(x1.double() + mlp(x2.double(), "resizer", len(dec.resizer.linears))), "flat_module", len(dec.flat_module.linears))
     assert_close(got, ref, tol=1e-5, what=f"decode rows F={F}")
+
+
+@pytest.mark.parametrize("B,T,L,dy", [(3, 64, 4, 2), (2, 70, 2, 1), (1, 257, 1, 2)])
+def test_decoder_side_matches_float64(B, T, L, dy):
+    """The decoder alone as one program each way (x6.decoder_side: r = 128 models whose attention is not the fused scaled-dot one,
+    e.g. the transformer attention of the shipped checkpoints): rows, the gradients wrt both inputs and every dW / db."""
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    r = 128
+    model = _build(r=r, L=L, dx=1, dy=dy, seed=T)
+    assert x6.decoder_side_usable(model, T)
+    g = torch.Generator().manual_seed(T)
+    R, X1 = torch.randn(B, T, r, generator=g) * 0.5, torch.randn(B, T, r, generator=g) * 0.5
+    w = torch.randn(B, T, 2 * dy, generator=g)
+    Rd, Xd = R.to(DEV).requires_grad_(True), X1.to(DEV).requires_grad_(True)
+    rows = x6.decoder_side(model, FN.pack_pt(Rd), FN.pack_pt(Xd), T)
+    assert tuple(rows.shape) == (B, T, 2 * dy)
+    (rows * w.to(DEV)).sum().backward()
+    d = lambda t: t.detach().double().cpu()  # noqa: E731
+    P = {k: d(v).requires_grad_(True) for k, v in model.named_parameters()}
+    lin = lambda x, pre: torch.nn.functional.linear(x, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+
+    def mlp(x, pre, n_lin):
+        h = torch.relu(lin(x, pre + ".to_hidden"))
+        for i in range(n_lin):
+            h = torch.relu(lin(h, f"{pre}.linears.{i}"))
+        return lin(h, pre + ".out")
+
+    Rr, Xr = R.double().requires_grad_(True), X1.double().requires_grad_(True)
+    ref = mlp(torch.relu(Xr + mlp(Rr, "decoder.resizer", len(model.decoder.resizer.linears))), "decoder.flat_module",
+              len(model.decoder.flat_module.linears))
+    (ref * w.double()).sum().backward()
+    assert_close(rows, ref, tol=1e-5, what="decoder rows")
+    assert_close(Rd.grad, Rr.grad, tol=1e-4, what="dR")
+    assert_close(Xd.grad, Xr.grad, tol=1e-4, what="dX1")
+    for k, p in model.named_parameters():
+        if k.startswith("decoder"):
+            assert p.grad is not None, k
+            assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
