@@ -497,8 +497,13 @@ class MultiheadAttender(nn.Module):
         if FN.mha_usable(self.kq_head_size, self.value_head_size, C):
             # 16-feature heads (the reference's default r_dim = 128, 8 heads): one launch on the projected tensors, the heads are
             # 16-feature slices of the PT32 tiles (csrc/mha_kernel.hip)
-            return FN.mha(self._project(queries_pt, B, T, self.query_transform), self._project(keys_pt, B, C, self.key_transform),
-                          self._project(values_pt, B, C, self.value_transform), B, C, T, H)
+            from . import x6
+
+            if x6.pair_linear_usable(self.key_transform, self.value_transform):  # (both on the context points: one launch)
+                Kp, Vp = x6.pair_linear(keys_pt, values_pt, C, self.key_transform, self.value_transform)
+            else:
+                Kp, Vp = self._project(keys_pt, B, C, self.key_transform), self._project(values_pt, B, C, self.value_transform)
+            return FN.mha(self._project(queries_pt, B, T, self.query_transform), Kp, Vp, B, C, T, H)
         Kh = FN.split_heads(self._project(keys_pt, B, C, self.key_transform), B, C, d, H)
         Qh = FN.split_heads(self._project(queries_pt, B, T, self.query_transform), B, T, d, H)
         Vh = FN.split_heads(self._project(values_pt, B, C, self.value_transform), B, C, self.value_size, H)

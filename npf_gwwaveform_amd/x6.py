@@ -599,6 +599,66 @@ def decoder_side(model, R_pt: torch.Tensor, X1_pt: torch.Tensor, T: int) -> torc
     return _DecoderSideFn.apply(R_pt, X1_pt, T, (len(rs.layers()), len(fm.linears) + 1), *params)
 
 
+class _PairLinearFn(torch.autograd.Function):
+    """(W_a a, W_b b) for two PT32 tensors of the same geometry and two bias-free F x F matrices as ONE program launch (two ops, each
+    with its own input), their dgrad as one launch, both weight gradients as one launch: the key and value projections of
+    MultiheadAttender (key_transform / value_transform, attention.py:397-404: Linear(bias=False) on the encoded context points
+    and on their representations)."""
+
+    @staticmethod
+    def forward(ctx, a_pt, b_pt, pts, Wa, Wb):
+        B, tiles = a_pt.shape[0], a_pt.shape[1]
+        F = Wa.shape[0]
+        dev = a_pt.device
+        train = any(ctx.needs_input_grad)
+        imgs = _weight_images([Wa, Wb], (1, 2) if train else (1,), F)
+        a_pt, b_pt = a_pt.contiguous(), b_pt.contiguous()
+        oa, ob = CH.pt_empty(B, tiles * 32, F, dev), CH.pt_empty(B, tiles * 32, F, dev)
+        prog = Program(B, tiles, per_task=False, width=F)
+        prog.op(in_pt=a_pt.detach(), img=imgs[0][0], w_ref=("shared", Wa), store_out=oa)
+        prog.op(in_pt=b_pt.detach(), img=imgs[0][1], w_ref=("shared", Wb), store_out=ob)
+        prog.tag = "key / value projections"
+        prog.launch()
+        ctx.geom = (B, tiles, F, pts)
+        ctx.set_materialize_grads(False)
+        if train:
+            ctx.save_for_backward(a_pt.detach(), b_pt.detach(), *imgs[1])
+        return oa, ob
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return (None,) * 5
+        B, tiles, F, pts = ctx.geom
+        a_pt, b_pt, ia, ib = ctx.saved_tensors
+        dev = a_pt.device
+        zeros = lambda: torch.zeros(CH.pt_shape(B, tiles * 32, F), dtype=torch.float32, device=dev)  # noqa: E731
+        ga = ga.contiguous() if ga is not None else zeros()
+        gb = gb.contiguous() if gb is not None else zeros()
+        da, db = CH.pt_empty(B, tiles * 32, F, dev), CH.pt_empty(B, tiles * 32, F, dev)
+        prog = Program(B, tiles, per_task=False, width=F)
+        prog.op(in_pt=ga, img=ia, store_out=da)
+        prog.op(in_pt=gb, img=ib, store_out=db)
+        prog.tag = "key / value projections dgrad"
+        prog.launch()
+        dWa, dWb = (torch.empty((F, F), dtype=torch.float32, device=dev) for _ in range(2))
+        # (``pts`` valid points: the padding points of the incoming gradients are zero or never written -- count only the valid ones)
+        CH.run_wgrad([dict(dZ=ga, A=a_pt, N=F, K=F, dW=dWa, db=None), dict(dZ=gb, A=b_pt, N=F, K=F, dW=dWb, db=None)], B, pts, dev,
+                     tag="key / value projection weight gradients")
+        return da, db, None, dWa, dWb
+
+
+def pair_linear_usable(lin_a, lin_b) -> bool:
+    F = lin_a.in_features
+    return (ENABLED and CH.COMPUTE_DTYPE == "fp32" and F in (128, 256) and lin_a.bias is None and lin_b.bias is None
+            and _square([lin_a, lin_b], F))
+
+
+def pair_linear(a_pt: torch.Tensor, b_pt: torch.Tensor, pts: int, lin_a, lin_b):
+    """(lin_a(a), lin_b(b)) on PT32 tensors [B, tiles, F/4, 32, 4] with ``pts`` valid points per task (``pair_linear_usable``)."""
+    return _PairLinearFn.apply(a_pt, b_pt, pts, lin_a.weight, lin_b.weight)
+
+
 def _width_of(model) -> int:
     """The feature width F of the model's wide layers if the x6 programs have an instance for it (128, 256), else 0."""
     F = getattr(model, "r_dim", 0)
