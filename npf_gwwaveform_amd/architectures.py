@@ -491,8 +491,9 @@ class MultiheadAttender(nn.Module):
         ch.input_pt(x_pt, lin.in_features).linear(lin.weight, lin.bias).output_pt()
         return ch.run()[0]
 
-    def _heads_attention(self, queries_pt, keys_pt, values_pt, B, C, T):
-        """K/Q/V projections, per-head scaled-dot attention, heads merged: PT32 [B, T, value_size]."""
+    def _heads_attention(self, queries_pt, keys_pt, values_pt, B, C, T, queries_proj=None):
+        """K/Q/V projections, per-head scaled-dot attention, heads merged: PT32 [B, T, value_size].  ``queries_proj``: the query
+        projection when the launch that encoded the queries already made it (x6.xenc_proj)."""
         H, d = self.n_heads, self.kq_size
         if FN.mha_usable(self.kq_head_size, self.value_head_size, C):
             # 16-feature heads (the reference's default r_dim = 128, 8 heads): one launch on the projected tensors, the heads are
@@ -503,7 +504,8 @@ class MultiheadAttender(nn.Module):
                 Kp, Vp = x6.pair_linear(keys_pt, values_pt, C, self.key_transform, self.value_transform)
             else:
                 Kp, Vp = self._project(keys_pt, B, C, self.key_transform), self._project(values_pt, B, C, self.value_transform)
-            return FN.mha(self._project(queries_pt, B, T, self.query_transform), Kp, Vp, B, C, T, H)
+            Qp = queries_proj if queries_proj is not None else self._project(queries_pt, B, T, self.query_transform)
+            return FN.mha(Qp, Kp, Vp, B, C, T, H)
         Kh = FN.split_heads(self._project(keys_pt, B, C, self.key_transform), B, C, d, H)
         Qh = FN.split_heads(self._project(queries_pt, B, T, self.query_transform), B, T, d, H)
         Vh = FN.split_heads(self._project(values_pt, B, C, self.value_transform), B, C, self.value_size, H)
@@ -516,9 +518,10 @@ class MultiheadAttender(nn.Module):
             Oh = self.dot.attend_pt(Qh, Kh, Vh, C, T)
         return FN.merge_heads(Oh, B, T, self.value_size, H)
 
-    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
+    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None,
+                  queries_proj=None):
         B = queries_pt.shape[0]
-        ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, n_queries)
+        ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, n_queries, queries_proj)
         if self.post_processor is not None:
             ctx = self._project(ctx, B, n_queries, self.post_processor)
         return ctx
@@ -546,9 +549,10 @@ class TransformerAttender(MultiheadAttender):
         self.mlp = MLP(self.out_size, self.out_size, hidden_size=self.out_size, activation=nn.ReLU())
         self.reset_parameters()
 
-    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None):
+    def attend_pt(self, queries_pt, keys_pt, values_pt, n_keys: int, n_queries: int, keys_tr=None, values_tr=None,
+                  queries_proj=None):
         B, T, d = queries_pt.shape[0], n_queries, self.out_size
-        ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, T)
+        ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, T, queries_proj)
         ln1, ln2 = self.layer_norm1, self.layer_norm2
         ch = Chain(B, T, queries_pt.device)
         ch.input_pt(ctx, d).add_pt(queries_pt).layernorm(ln1.weight, ln1.bias, ln1.eps).output_pt()

@@ -130,6 +130,7 @@ class PTensor:
     F: int                                # valid features
     tr: Optional[torch.Tensor] = None     # feature-major copy [n_tasks, F, 32*tiles] (``Chain.store_tr``)
     img: Optional[Tuple[torch.Tensor, torch.Tensor]] = None  # bf16 row / transposed images (bf16 compute mode)
+    proj: Optional[torch.Tensor] = None   # PT32: the attender's query projection of these points, made by their producer (x6.xenc_proj)
 
     def __post_init__(self):
         want = pt_shape(self.t.shape[0], self.pts, self.F)

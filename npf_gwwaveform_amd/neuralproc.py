@@ -151,6 +151,13 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
             R = self._encode_globally_pt(Xc_pt, Y_cntxt, B, C)
         if fused_t:
             Xt_pt, self._X_trgt_raw = None, X_trgt  # (the target side runs as one x6 program from the raw features)
+        elif self._xenc_with_query_projection(C, T):
+            # multihead / transformer attention with 16-wide heads: the target x-encoder and the attender's query projection as
+            # one x6 program (x6.xenc_proj)
+            from . import x6
+
+            Xt_pt, q_proj = x6.xenc_proj(self, X_trgt, self.attender.query_transform)
+            Xt_pt.proj = q_proj
         else:
             Xt_pt = self._xenc_pt(X_trgt)
         if self.encoded_path in ["latent", "both"]:
@@ -203,6 +210,15 @@ class NeuralProcessFamily(nn.Module, abc.ABC):
     def _fused_target_side(self, C, T) -> bool:
         """Does ``forward`` hand the whole target side (x-encoder, attention, decoder) to one x6 program (x6.py)."""
         return False
+
+    def _xenc_with_query_projection(self, C, T) -> bool:
+        """Does ``forward`` hand the target x-encoder + the attender's query projection to one x6 program (x6.xenc_proj)."""
+        from . import x6
+
+        att = getattr(self, "attender", None)
+        if not (self._attentive and isinstance(att, MultiheadAttender) and C > 0):
+            return False
+        return FN.mha_usable(att.kq_head_size, att.value_head_size, C) and x6.xenc_proj_usable(self, att.query_transform, T)
 
     def _fused_context_side(self, C) -> bool:
         """Does ``forward`` hand x-encoder + XY-encoder of the context points to one x6 program (x6.py)."""
@@ -506,7 +522,7 @@ class AttnCNP(NeuralProcessFamily):
         from . import chain as _chain
 
         if not isinstance(self.attender, DotAttender):  # learned projections: its own launches
-            ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T), self.r_dim)
+            ch.input_pt(self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, queries_proj=Xt_pt.proj), self.r_dim)
         elif _chain.COMPUTE_DTYPE == "bf16":
             if Xc_pt.img is not None and R.img is not None and self.attender.fits_fused(C):
                 # bf16 compute mode with bf16 images of keys / values: attention and decoder in one bf16 chain
@@ -537,7 +553,7 @@ class AttnCNP(NeuralProcessFamily):
 
             if x6.decoder_side_usable(self, T):
                 # learned projections (multihead / transformer attention): its own launches, then the decoder as one x6 program
-                return x6.decoder_side(self, self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T), Xt_pt.t, T)
+                return x6.decoder_side(self, self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, queries_proj=Xt_pt.proj), Xt_pt.t, T)
         ch = Chain(B, T, Xt_pt.t.device, wg_per_task=True)
         if C == 0:
             ch.input_pt(torch.zeros(pt_shape(B, T, self.r_dim), device=Xt_pt.t.device), self.r_dim)

@@ -659,6 +659,135 @@ def pair_linear(a_pt: torch.Tensor, b_pt: torch.Tensor, pts: int, lin_a, lin_b):
     return _PairLinearFn.apply(a_pt, b_pt, pts, lin_a.weight, lin_b.weight)
 
 
+class _XEncProjFn(torch.autograd.Function):
+    """(X_enc, Q) PT32 = x_encoder(X), query_transform(X_enc) from the raw features X [B, P, dx] (P whole tiles) in one launch, the
+    dgrad of both in one launch, their weight gradients in one: the target side in front of a multihead / transformer attention
+    (MLP.forward mlp.py:95-109; MultiheadAttender.query_transform, attention.py:397-404, a Linear with bias).  ``n_x`` = F -> F
+    layers of the x-encoder behind its first layer; params = W, b pairs: x-encoder (first layer, the F -> F ones), projection."""
+
+    @staticmethod
+    def forward(ctx, X, n_x, *params):
+        B, P, dx = X.shape
+        dev = X.device
+        tiles = P // 32
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        W1, b1 = Ws[0], bs[0]
+        x_W, x_b = Ws[1:1 + n_x], bs[1:1 + n_x]
+        Wq, bq = Ws[-1], bs[-1]
+        F = Wq.shape[0]
+        train = any(ctx.needs_input_grad)
+        imgs = _weight_images([*x_W, Wq], (1, 2) if train else (1,), F)
+        fw = imgs[0]
+        X4 = _pad_rows4(X.detach())
+        pt = lambda: CH.pt_empty(B, P, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F)
+        acts, bits = [], []
+        h1 = pt() if train else None
+        bits_h1 = _bits(B, tiles, dev) if train else None
+        X_enc, Q = pt(), pt()
+        for i in range(n_x):
+            last = i == n_x - 1
+            o = dict(img=fw[i], w_ref=("shared", x_W[i]), bias=x_b[i].detach() if x_b[i] is not None else None, relu=not last)
+            if i == 0:
+                o.update(in_rows=X4, in_w=_first_layer_matrix(W1, F), in_b=b1.detach() if b1 is not None else None, in_relu=True,
+                         store_in=h1, store_in_bits=bits_h1)
+            if last:
+                o["store_out"] = X_enc
+            elif train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                acts.append(o["store_out"])
+                bits.append(o["store_bits"])
+            prog.op(**o)
+        prog.op(img=fw[n_x], w_ref=("shared", Wq), bias=bq.detach() if bq is not None else None, store_out=Q)
+        prog.tag = "x-encoder + query projection"
+        prog.launch()
+        ctx.geom = (B, P, tiles, dx, F)
+        ctx.n_x = n_x
+        ctx.has_b = [b is not None for b in bs]
+        ctx.set_materialize_grads(False)
+        if train:
+            ctx.save_for_backward(X4, h1, bits_h1, X_enc, *acts, *bits, *imgs[1])
+        return X_enc, Q
+
+    @staticmethod
+    def backward(ctx, gX, gQ):
+        n_x = ctx.n_x
+        n_par = 2 * (n_x + 2)
+        if gX is None and gQ is None:
+            return (None,) * (2 + n_par)
+        B, P, tiles, dx, F = ctx.geom
+        sv = list(ctx.saved_tensors)
+        X4, h1, bits_h1, X_enc = sv[:4]
+        acts, bits, bw = sv[4:4 + n_x - 1], sv[4 + n_x - 1:4 + 2 * (n_x - 1)], sv[4 + 2 * (n_x - 1):]
+        dev = X4.device
+        pt = lambda: CH.pt_empty(B, P, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F)
+        jobs, grads = [], [None] * n_par
+
+        def wjob(pos, dZ, A, N, K):
+            dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            db = torch.empty((N,), dtype=torch.float32, device=dev) if ctx.has_b[pos] else None
+            jobs.append(dict(dZ=dZ, A=A, N=N, K=K, dW=dW, db=db))
+            grads[2 * pos], grads[2 * pos + 1] = dW, db
+            return dW
+
+        if gQ is not None:
+            gQ = gQ.contiguous()
+            prog.op(in_pt=gQ, img=bw[n_x])          # the projection's dgrad; the x-encoder's own gradient joins in front of the next op
+            wjob(n_x + 1, gQ, X_enc, F, F)
+            first = dict(pre_add=gX.contiguous()) if gX is not None else {}
+        else:
+            first = dict(in_pt=gX.contiguous())
+        x_in = [h1, *acts]
+        for i in range(n_x - 1, -1, -1):
+            dz = pt()
+            o = dict(store_in=dz, img=bw[i])
+            if i == n_x - 1:
+                o.update(first)
+            else:
+                o["mask_bits"] = bits[i]
+            prog.op(**o)
+            wjob(1 + i, dz, x_in[i], F, F)
+        dz1 = pt()
+        prog.op(mask_bits=bits_h1, store_in=dz1)
+        dW1p = wjob(0, dz1, FN._pack(X4), F, 4)
+        prog.tag = "x-encoder + query projection dgrad"
+        prog.launch()
+        CH.run_wgrad(jobs, B, P, dev, tag="x-encoder + query projection weight gradients")
+        if dx != 4:
+            grads[0] = dW1p[:, :dx].contiguous()
+        return (None, None, *grads)
+
+
+def xenc_proj_usable(model, lin_q, T: int) -> bool:
+    """Does ``xenc_proj`` cover this model: fp32, stock MLP x-encoder (<= 4 inputs) with F-wide layers, F in (128, 256), a F -> F
+    projection, no residual / dropout."""
+    from .architectures import MLP
+
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32") or T <= 0:
+        return False
+    F = _width_of(model)
+    xe = model.x_encoder
+    if not F or not (isinstance(xe, MLP) and xe.input_size <= 4 and xe.hidden_size == F and xe.output_size == F
+                     and not xe.is_res and not (xe.dropout_p > 0 and xe.training)):
+        return False
+    return lin_q.in_features == F and lin_q.out_features == F and len(xe.linears) + 3 <= L.NPF_X6_MAX_OPS
+
+
+def xenc_proj(model, X: torch.Tensor, lin_q):
+    """(encoded points as a :class:`~chain.PTensor`, their projection as a PT32 tensor) -- ``xenc_proj_usable``."""
+    xe = model.x_encoder
+    lins = [xe.to_hidden, *xe.linears, xe.out, lin_q]
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    T = X.shape[1]
+    if T % 32:
+        X = torch.nn.functional.pad(X, (0, 0, 0, CH.pad32(T) - T))
+    Xe, Q = _XEncProjFn.apply(X, len(xe.linears) + 1, *params)
+    return CH.PTensor(Xe, T, model.r_dim), Q
+
+
 def _width_of(model) -> int:
     """The feature width F of the model's wide layers if the x6 programs have an instance for it (128, 256), else 0."""
     F = getattr(model, "r_dim", 0)
