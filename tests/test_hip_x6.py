@@ -282,3 +282,68 @@ def test_decoder_side_matches_float64(B, T, L, dy):
         if k.startswith("decoder"):
             assert p.grad is not None, k
             assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("B,C,r", [(3, 128, 128), (2, 37, 128), (2, 200, 256)])
+def test_pair_linear_matches_float64(B, C, r):
+    """Two bias-free r x r projections of two PT32 tensors as one launch each way (x6.pair_linear: the key / value projections of
+    MultiheadAttender, attention.py:397-404)."""
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    torch.manual_seed(C)
+    la, lb = torch.nn.Linear(r, r, bias=False).to(DEV), torch.nn.Linear(r, r, bias=False).to(DEV)
+    assert x6.pair_linear_usable(la, lb)
+    g = torch.Generator().manual_seed(B + C)
+    a, b = torch.randn(B, C, r, generator=g), torch.randn(B, C, r, generator=g)
+    wa, wb = torch.randn(B, C, r, generator=g), torch.randn(B, C, r, generator=g)
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    oa, ob = x6.pair_linear(FN.pack_pt(ad), FN.pack_pt(bd), C, la, lb)
+    oa, ob = FN.unpack_pt(oa, C, r), FN.unpack_pt(ob, C, r)
+    ((oa * wa.to(DEV)).sum() + (ob * wb.to(DEV)).sum()).backward()
+    Wa, Wb = la.weight.detach().double().cpu().requires_grad_(True), lb.weight.detach().double().cpu().requires_grad_(True)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ra, rb = ar @ Wa.t(), br @ Wb.t()
+    ((ra * wa.double()).sum() + (rb * wb.double()).sum()).backward()
+    assert_close(oa, ra, tol=1e-5, what="first projection")
+    assert_close(ob, rb, tol=1e-5, what="second projection")
+    assert_close(ad.grad, ar.grad, tol=1e-4, what="d first input")
+    assert_close(bd.grad, br.grad, tol=1e-4, what="d second input")
+    assert_close(la.weight.grad, Wa.grad, tol=1e-4, what="dW first")
+    assert_close(lb.weight.grad, Wb.grad, tol=1e-4, what="dW second")
+
+
+@pytest.mark.parametrize("B,T,L,dx,r", [(3, 64, 2, 1, 128), (2, 70, 1, 2, 128), (2, 96, 3, 1, 256)])
+def test_xenc_proj_matches_float64(B, T, L, dx, r):
+    """x-encoder + a projection with bias of its output as one launch each way (x6.xenc_proj: the targets in front of a
+    multihead / transformer attention, mlp.py:95-109 + MultiheadAttender.query_transform)."""
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    model = _build(r=r, L=L, dx=dx, dy=2, seed=T)
+    torch.manual_seed(T)
+    lq = torch.nn.Linear(r, r, bias=True).to(DEV)
+    assert x6.xenc_proj_usable(model, lq, T)
+    g = torch.Generator().manual_seed(T + B)
+    X = torch.rand(B, T, dx, generator=g) * 2 - 1
+    we, wq = torch.randn(B, T, r, generator=g), torch.randn(B, T, r, generator=g)
+    Xe, Q = x6.xenc_proj(model, X.to(DEV), lq)
+    xe, q = FN.unpack_pt(Xe.t, T, r), FN.unpack_pt(Q, T, r)
+    ((xe * we.to(DEV)).sum() + (q * wq.to(DEV)).sum()).backward()
+    d = lambda t: t.detach().double().cpu()  # noqa: E731
+    P = {k: d(v).requires_grad_(True) for k, v in model.named_parameters() if k.startswith("x_encoder")}
+    Wq, bq = d(lq.weight).requires_grad_(True), d(lq.bias).requires_grad_(True)
+    lin = lambda x, pre: torch.nn.functional.linear(x, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+    h = torch.relu(lin(X.double(), "x_encoder.to_hidden"))
+    for i in range(len(model.x_encoder.linears)):
+        h = torch.relu(lin(h, f"x_encoder.linears.{i}"))
+    re = lin(h, "x_encoder.out")
+    rq = re @ Wq.t() + bq
+    ((re * we.double()).sum() + (rq * wq.double()).sum()).backward()
+    assert_close(xe, re, tol=1e-5, what="encoded points")
+    assert_close(q, rq, tol=1e-5, what="projection")
+    assert_close(lq.weight.grad, Wq.grad, tol=1e-4, what="dW projection")
+    assert_close(lq.bias.grad, bq.grad, tol=1e-4, what="db projection")
+    for k, p in model.named_parameters():
+        if k.startswith("x_encoder"):
+            assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
