@@ -58,19 +58,21 @@ __device__ __forceinline__ void mha_stage(const float* __restrict__ K, const flo
   }
 }
 
-// One workgroup = one (task, head, 64 queries); a wave owns 16 queries.
+// One workgroup = one (task, head, up to 256 queries): the head's keys / values are staged once, a wave takes 16 queries per round.
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                      const float* __restrict__ V, float* __restrict__ O, float* __restrict__ lse,
                                                      int n_tasks, int n_heads, int C, int T, int Fp, float scale) {
   __shared__ float Ks[kMhaMaxKeys * kMhaLd], Vs[kMhaMaxKeys * kMhaLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int qblocks = (T + 63) >> 6;
+  const int qblocks = (T + 255) >> 8;
   const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks, h = bh % n_heads, b = bh / n_heads;
   const int tilesC = (C + 31) >> 5, tilesT = (T + 31) >> 5, Cp = (C + 15) & ~15, nblk = Cp >> 4;
   mha_stage(K, V, b, h, tilesC, Fp, C, Cp, Ks, Vs, tid, 256);
   __syncthreads();
-  const int q = qb * 64 + wave * 16 + c;
+  for (int round = 0; round < 4; ++round) {
+  const int q = qb * 256 + round * 64 + wave * 16 + c;
+  if (qb * 256 + round * 64 + wave * 16 >= T) break;  // (wave-uniform)
   const bool live = q < T;
   // the lane's query as an operand: Q[q][4 kc + g]
   float Qq[4];
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
   if (live) {
     *(f32x4*)(O + mha_pt(b, tilesT, Fp, q, kMhaD * h + 4 * g)) = o;
     if (g == 0 && lse != nullptr) lse[((size_t)b * n_heads + h) * T + q] = mx + logf(sum);
+  }
   }
 }
 
@@ -255,7 +258,7 @@ extern "C" int npf_mha_fwd(const float* q, const float* k, const float* v, int32
   const int rc = mha_check(q, k, v, out, n_tasks, n_heads, n_keys, n_queries, F);
   if (rc != NPF_OK) return rc;
   const int Fp = npf::round_up(F, 32);
-  const int qblocks = (n_queries + 63) / 64;
+  const int qblocks = (n_queries + 255) / 256;
   hipLaunchKernelGGL(npf::mha_fwd_kernel, dim3(n_tasks * n_heads * qblocks), dim3(256), 0, (hipStream_t)stream, q, k, v, out, lse,
                      n_tasks, n_heads, n_keys, n_queries, Fp, 1.0f / sqrtf((float)npf::kMhaD));
   NPF_CHECK_LAUNCH();
