@@ -276,6 +276,16 @@ int npf_mha_bwd(const float *q, const float *k, const float *v, const float *out
                 int32_t n_tasks, int32_t n_heads, int32_t n_keys, int32_t n_queries, int32_t F, float *d_q, float *d_k, float *d_v,
                 void *stream);
 
+/* y = LayerNorm(a + b) over the F features of every point (F % 4 == 0, F <= 256), PT32 tensors [n_tasks][pts_per_task][F]:
+ * TransformerAttender.forward's layer_norm1(context + queries) (npf/architectures/attention.py:566-575; nn.LayerNorm: biased
+ * variance, eps inside the root, gamma / beta [F]).  stats [n_tasks * tiles * 32][2] = (mean, 1 / std) per point, or NULL at inference.
+ * npf_add_layernorm_bwd: dx (the gradient of a and of b alike; zero at the padding points) and partials [n_tasks * tiles][2][F] = the
+ * tile's sums of dy * xhat and of dy, which the caller adds up over the tiles to dgamma and dbeta. */
+int npf_add_layernorm_fwd(const float *a, const float *b, const float *gamma, const float *beta, float eps, int32_t n_tasks,
+                          int32_t pts_per_task, int32_t F, float *y, float *stats, void *stream);
+int npf_add_layernorm_bwd(const float *a, const float *b, const float *gamma, const float *stats, const float *dy, int32_t n_tasks,
+                          int32_t pts_per_task, int32_t F, float *dx, float *partials, void *stream);
+
 /* Context / target selection (CntxtTrgtGetter.select, npf/utils/datasplit.py:246-255: torch.gather along
  * the points of X and y with the same indices): out_x[b][i][:] = x[b][idx[b][i]][:], same for y.
  * idx: int64 [n_tasks][n_sel], every entry in [0, n_points) (checked on the host side). */

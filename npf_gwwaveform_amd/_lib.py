@@ -119,6 +119,8 @@ SIGNATURES = {
     "npf_b16_task_images": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "npf_mha_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "npf_mha_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "npf_add_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, C.c_float, _i32, _i32, _i32, _p, _p, _p]),
+    "npf_add_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "npf_version": (C.c_int, []),
 }
 

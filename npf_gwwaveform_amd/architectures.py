@@ -554,9 +554,12 @@ class TransformerAttender(MultiheadAttender):
         B, T, d = queries_pt.shape[0], n_queries, self.out_size
         ctx = self._heads_attention(queries_pt, keys_pt, values_pt, B, n_keys, T, queries_proj)
         ln1, ln2 = self.layer_norm1, self.layer_norm2
-        ch = Chain(B, T, queries_pt.device)
-        ch.input_pt(ctx, d).add_pt(queries_pt).layernorm(ln1.weight, ln1.bias, ln1.eps).output_pt()
-        x = ch.run()[0]
+        if FN.add_layernorm_usable(d):
+            x = FN.add_layernorm(ctx, queries_pt, ln1, B, T)  # (a bandwidth-bound kernel of its own: csrc/ln_kernel.hip)
+        else:
+            ch = Chain(B, T, queries_pt.device)
+            ch.input_pt(ctx, d).add_pt(queries_pt).layernorm(ln1.weight, ln1.bias, ln1.eps).output_pt()
+            x = ch.run()[0]
         # (the residual re-reads x, so the MLP block is its own launch)
         ls = self.mlp.layers()
         ch = Chain(B, T, queries_pt.device)

@@ -287,3 +287,63 @@ def mha(q_pt: torch.Tensor, k_pt: torch.Tensor, v_pt: torch.Tensor, n_tasks: int
     """PT32 [n_tasks, n_queries, 16 n_heads]: per-head scaled-dot attention of the projected queries over the projected keys /
     values (``mha_usable``), no split / merge of heads in memory."""
     return _MhaFn.apply(q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads)
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    """LayerNorm(a + b) over the features on PT32 tensors (``npf_add_layernorm_fwd`` / ``_bwd``; the first LayerNorm of
+    TransformerAttender.forward, npf/architectures/attention.py:566-575)."""
+
+    @staticmethod
+    def forward(ctx, a_pt, b_pt, gamma, beta, eps, n_tasks, pts, F):
+        from . import chain as CH
+
+        a_pt, b_pt = a_pt.contiguous(), b_pt.contiguous()
+        tiles = tiles_of(pts)
+        train = any(ctx.needs_input_grad[:4])
+        y = (torch.zeros if pad32(F) != F else torch.empty)(CH.pt_shape(n_tasks, pts, F), dtype=torch.float32, device=a_pt.device)
+        stats = torch.empty((n_tasks * tiles * 32, 2), dtype=torch.float32, device=a_pt.device) if train else None
+        g, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        if CH.PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().npf_add_layernorm_fwd(L.ptr(a_pt), L.ptr(b_pt), L.ptr(g), L.ptr(bt), float(eps), n_tasks, pts, F, L.ptr(y),
+                                               L.ptr(stats) if stats is not None else None, L.stream_ptr()), "npf_add_layernorm_fwd")
+        if CH.PROFILE is not None:
+            ev1.record()
+            CH.PROFILE.append(("add_layernorm_fwd_kernel", 0, ev0, ev1, 12 * n_tasks * tiles * 32 * F, "LayerNorm(context + queries)"))
+        ctx.geom = (n_tasks, pts, F, tiles)
+        if train:
+            ctx.save_for_backward(a_pt, b_pt, g, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import chain as CH
+
+        n_tasks, pts, F, tiles = ctx.geom
+        a_pt, b_pt, g, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = (torch.zeros if pad32(F) != F else torch.empty)(CH.pt_shape(n_tasks, pts, F), dtype=torch.float32, device=dy.device)
+        partials = torch.empty((n_tasks * tiles, 2, F), dtype=torch.float32, device=dy.device)
+        if CH.PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().npf_add_layernorm_bwd(L.ptr(a_pt), L.ptr(b_pt), L.ptr(g), L.ptr(stats), L.ptr(dy), n_tasks, pts, F, L.ptr(dx),
+                                               L.ptr(partials), L.stream_ptr()), "npf_add_layernorm_bwd")
+        sums = partials.sum(0)
+        if CH.PROFILE is not None:
+            ev1.record()
+            CH.PROFILE.append(("add_layernorm_bwd_kernel", 0, ev0, ev1, 16 * n_tasks * tiles * 32 * F, "LayerNorm(context + queries) backward"))
+        return dx, dx, sums[0], sums[1], None, None, None, None
+
+
+def add_layernorm_usable(F: int) -> bool:
+    from . import chain as CH
+
+    return MHA_ENABLED and CH.COMPUTE_DTYPE == "fp32" and F % 4 == 0 and F <= 256
+
+
+def add_layernorm(a_pt: torch.Tensor, b_pt: torch.Tensor, ln: torch.nn.LayerNorm, n_tasks: int, pts: int) -> torch.Tensor:
+    """PT32 LayerNorm(a + b) with the module's gamma / beta / eps (``add_layernorm_usable``)."""
+    F = ln.normalized_shape[0]
+    return _AddLayerNormFn.apply(a_pt, b_pt, ln.weight, ln.bias, ln.eps, n_tasks, pts, F)

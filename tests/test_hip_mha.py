@@ -62,3 +62,30 @@ def test_mha_rejects_other_head_sizes_and_too_many_keys():
     lib = L.load()
     assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 4, 32, 32, 128, L.ptr(x), None, None) == -1   # 128 != 16 * 4
     assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 8, 257, 32, 128, L.ptr(x), None, None) == -1  # keys > 256
+
+
+@pytest.mark.parametrize("B,T,F", [(3, 256, 128), (2, 70, 128), (2, 33, 32), (1, 5, 256), (2, 64, 48)])
+def test_add_layernorm_matches_float64(B, T, F):
+    """LayerNorm(a + b) on PT32 tensors (npf_add_layernorm_fwd / _bwd; TransformerAttender.forward's first LayerNorm,
+    attention.py:566-575) against torch.nn.functional.layer_norm in float64: output, both input gradients, dgamma, dbeta."""
+    from npf_gwwaveform_amd import functional as FN
+
+    torch.manual_seed(T)
+    ln = torch.nn.LayerNorm(F).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(B + T)
+    a, b, w = (torch.randn(B, T, F, generator=g) for _ in range(3))
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = FN.unpack_pt(FN.add_layernorm(FN.pack_pt(ad), FN.pack_pt(bd), ln, B, T), T, F)
+    (y * w.to(DEV)).sum().backward()
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    gam, bet = ln.weight.detach().double().cpu().requires_grad_(True), ln.bias.detach().double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(ar + br, (F,), gam, bet, ln.eps)
+    (ref * w.double()).sum().backward()
+    assert_close(y, ref, tol=1e-5, what="LayerNorm(a + b)")
+    assert_close(ad.grad, ar.grad, tol=1e-4, what="da")
+    assert_close(bd.grad, br.grad, tol=1e-4, what="db")
+    assert_close(ln.weight.grad, gam.grad, tol=1e-4, what="dgamma")
+    assert_close(ln.bias.grad, bet.grad, tol=1e-4, what="dbeta")
