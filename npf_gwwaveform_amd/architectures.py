@@ -560,6 +560,11 @@ class TransformerAttender(MultiheadAttender):
             ch = Chain(B, T, queries_pt.device)
             ch.input_pt(ctx, d).add_pt(queries_pt).layernorm(ln1.weight, ln1.bias, ln1.eps).output_pt()
             x = ch.run()[0]
+        from . import x6
+
+        if FN.add_layernorm_usable(d) and x6.mlp_pt_usable(self.mlp):
+            # the MLP block as one x6 program each way, LayerNorm(x + MLP(x)) on the bandwidth-bound kernel
+            return FN.add_layernorm(x, x6.mlp_pt(self.mlp, x, T), ln2, B, T)
         # (the residual re-reads x, so the MLP block is its own launch)
         ls = self.mlp.layers()
         ch = Chain(B, T, queries_pt.device)

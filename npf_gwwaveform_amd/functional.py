@@ -310,7 +310,7 @@ class _AddLayerNormFn(torch.autograd.Function):
                                                L.ptr(stats) if stats is not None else None, L.stream_ptr()), "npf_add_layernorm_fwd")
         if CH.PROFILE is not None:
             ev1.record()
-            CH.PROFILE.append(("add_layernorm_fwd_kernel", 0, ev0, ev1, 12 * n_tasks * tiles * 32 * F, "LayerNorm(context + queries)"))
+            CH.PROFILE.append(("add_layernorm_fwd_kernel", 0, ev0, ev1, 12 * n_tasks * tiles * 32 * F, "LayerNorm(a + b)"))
         ctx.geom = (n_tasks, pts, F, tiles)
         if train:
             ctx.save_for_backward(a_pt, b_pt, g, stats)
@@ -333,7 +333,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         sums = partials.sum(0)
         if CH.PROFILE is not None:
             ev1.record()
-            CH.PROFILE.append(("add_layernorm_bwd_kernel", 0, ev0, ev1, 16 * n_tasks * tiles * 32 * F, "LayerNorm(context + queries) backward"))
+            CH.PROFILE.append(("add_layernorm_bwd_kernel", 0, ev0, ev1, 16 * n_tasks * tiles * 32 * F, "LayerNorm(a + b) backward"))
         return dx, dx, sums[0], sums[1], None, None, None, None
 
 

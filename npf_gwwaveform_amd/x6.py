@@ -788,6 +788,101 @@ def xenc_proj(model, X: torch.Tensor, lin_q):
     return CH.PTensor(Xe, T, model.r_dim), Q
 
 
+class _MlpPtFn(torch.autograd.Function):
+    """``MLP.forward`` (mlp.py:95-109: to_hidden -> relu -> [linears -> relu]* -> out) on a PT32 tensor whose layers are all F x F,
+    as one program launch each way + one weight-gradient launch: the MLP block of TransformerAttender (attention.py:576-588) at
+    F = 128 / 256.  params = W, b pairs in layer order; ReLU behind all but the last."""
+
+    @staticmethod
+    def forward(ctx, x_pt, pts, *params):
+        B, tiles = x_pt.shape[0], x_pt.shape[1]
+        dev = x_pt.device
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        n, F = len(Ws), Ws[0].shape[0]
+        train = any(ctx.needs_input_grad)
+        imgs = _weight_images(Ws, (1, 2) if train else (1,), F)
+        x_pt = x_pt.contiguous()
+        pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F)
+        acts, bits = [], []
+        y = pt()
+        for i in range(n):
+            last = i == n - 1
+            o = dict(img=imgs[0][i], w_ref=("shared", Ws[i]), bias=bs[i].detach() if bs[i] is not None else None, relu=not last)
+            if i == 0:
+                o["in_pt"] = x_pt.detach()
+            if last:
+                o["store_out"] = y
+            elif train:
+                o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
+                acts.append(o["store_out"])
+                bits.append(o["store_bits"])
+            prog.op(**o)
+        prog.tag = "MLP block forward"
+        prog.launch()
+        ctx.geom = (B, tiles, F, pts, n)
+        ctx.has_b = [b is not None for b in bs]
+        ctx.set_materialize_grads(False)
+        if train:
+            ctx.save_for_backward(x_pt.detach(), *acts, *bits, *imgs[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, tiles, F, pts, n = ctx.geom
+        if g is None:
+            return (None,) * (2 + 2 * n)
+        sv = list(ctx.saved_tensors)
+        x_pt, acts, bits, bw = sv[0], sv[1:n], sv[n:2 * n - 1], sv[2 * n - 1:]
+        dev = g.device
+        g = g.contiguous()
+        pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
+        prog = Program(B, tiles, per_task=False, width=F)
+        dz = [None] * n
+        dx = pt()
+        for i in range(n - 1, -1, -1):
+            o = dict(img=bw[i])
+            if i == n - 1:
+                o["in_pt"], dz[i] = g, g       # (no activation behind the last layer: its dZ is the incoming gradient)
+            else:
+                dz[i] = pt()
+                o.update(mask_bits=bits[i], store_in=dz[i])
+            if i == 0:
+                o["store_out"] = dx
+            prog.op(**o)
+        prog.tag = "MLP block dgrad"
+        prog.launch()
+        ins = [x_pt, *acts]
+        jobs, grads = [], []
+        for i in range(n):
+            dW = torch.empty((F, F), dtype=torch.float32, device=dev)
+            db = torch.empty((F,), dtype=torch.float32, device=dev) if ctx.has_b[i] else None
+            jobs.append(dict(dZ=dz[i], A=ins[i], N=F, K=F, dW=dW, db=db))
+            grads += [dW, db]
+        CH.run_wgrad(jobs, B, pts, dev, tag="MLP block weight gradients")
+        return (dx, None, *grads)
+
+
+def mlp_pt_usable(mlp) -> bool:
+    """Does ``mlp_pt`` cover this MLP: fp32 mode, every layer F x F with F in (128, 256), no residual / dropout."""
+    from .architectures import MLP
+
+    if not (ENABLED and CH.COMPUTE_DTYPE == "fp32" and isinstance(mlp, MLP)):
+        return False
+    F = mlp.input_size
+    if F not in (128, 256) or mlp.is_res or (mlp.dropout_p > 0 and mlp.training):
+        return False
+    return _square(mlp.layers(), F) and len(mlp.layers()) <= L.NPF_X6_MAX_OPS
+
+
+def mlp_pt(mlp, x_pt: torch.Tensor, pts: int) -> torch.Tensor:
+    """``mlp(x)`` on a PT32 tensor [B, tiles, F/4, 32, 4] (``mlp_pt_usable``)."""
+    params = []
+    for lin in mlp.layers():
+        params += [lin.weight, lin.bias]
+    return _MlpPtFn.apply(x_pt, pts, *params)
+
+
 def _width_of(model) -> int:
     """The feature width F of the model's wide layers if the x6 programs have an instance for it (128, 256), else 0."""
     F = getattr(model, "r_dim", 0)

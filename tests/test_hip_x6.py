@@ -347,3 +347,37 @@ def test_xenc_proj_matches_float64(B, T, L, dx, r):
     for k, p in model.named_parameters():
         if k.startswith("x_encoder"):
             assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("B,T,L,r", [(3, 64, 1, 128), (2, 70, 3, 128), (2, 33, 1, 256)])
+def test_mlp_pt_matches_float64(B, T, L, r):
+    """An MLP with r x r layers on a PT32 tensor as one launch each way (x6.mlp_pt: the MLP block of TransformerAttender,
+    attention.py:576-588; MLP.forward mlp.py:95-109)."""
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    torch.manual_seed(T + L)
+    mlp = A.MLP(r, r, hidden_size=r, n_hidden_layers=L).to(DEV)
+    with torch.no_grad():
+        for k, p in mlp.named_parameters():
+            if k.endswith(".bias"):
+                p.uniform_(-0.05, 0.05)
+    assert x6.mlp_pt_usable(mlp)
+    g = torch.Generator().manual_seed(B + T)
+    x, w = torch.randn(B, T, r, generator=g) * 0.7, torch.randn(B, T, r, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    y = FN.unpack_pt(x6.mlp_pt(mlp, FN.pack_pt(xd), T), T, r)
+    (y * w.to(DEV)).sum().backward()
+    P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in mlp.named_parameters()}
+    lin = lambda t, pre: torch.nn.functional.linear(t, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+    xr = x.double().requires_grad_(True)
+    h = torch.relu(lin(xr, "to_hidden"))
+    for i in range(len(mlp.linears)):
+        h = torch.relu(lin(h, f"linears.{i}"))
+    ref = lin(h, "out")
+    (ref * w.double()).sum().backward()
+    assert_close(y, ref, tol=1e-5, what="MLP output")
+    assert_close(xd.grad, xr.grad, tol=1e-4, what="dx")
+    for k, p in mlp.named_parameters():
+        assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
