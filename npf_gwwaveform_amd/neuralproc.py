@@ -617,6 +617,12 @@ class AttnLNP(LatentNeuralProcessFamily, AttnCNP):
             from . import x6
 
             return x6.target_side(self, self._X_trgt_raw, Xc_pt, R, zb=zb)
+        if n_z == 1 and C > 0 and not isinstance(self.attender, DotAttender) and self.z_dim == self.r_dim:
+            from . import x6
+
+            if x6.decoder_side_usable(self, T):  # (attention with learned projections, then merge_r_z + decoder as one program)
+                R_t = self.attender.attend_pt(Xt_pt.t, Xc_pt.t, R.t, C, T, queries_proj=Xt_pt.proj)
+                return x6.decoder_side(self, R_t, Xt_pt.t, T, zb=zb[:, :r].contiguous())
         if n_z == 1:
             ch = Chain(B, T, dev, wg_per_task=True)
             if C == 0:

@@ -471,12 +471,13 @@ class _DecoderSideFn(torch.autograd.Function):
     """rows [B, T, n_out] = decoder(x1, R) = flat(relu(x1 + resizer(R))) + output layer (MergeFlatInputs.forward, encoders.py:175-183,
     as ``NeuralProcessFamily.decode`` calls it, base.py:327-367) from PT32 tensors: ONE launch forward, ONE for its dgrad, then the
     weight-gradient jobs -- the decoder half of ``_TargetSideFn`` for models whose attention is not the fused scaled-dot one
-    (multihead / transformer attention, more than 256 keys).  ``spec`` = (n_res, n_flat): F -> F layers of the resizer, of the flat
-    MLP in front of its output layer; params = W, b pairs: resizer, flat, output layer."""
+    (multihead / transformer attention, more than 256 keys).  ``spec`` = (n_mrz, n_res, n_flat): AttnLNP's latent merge in front
+    (0 or 1: relu(W_R R + zb[task]), base.py:554-575, ``zb`` [B, F] the latent half as a per-task bias), F -> F layers of the
+    resizer, of the flat MLP in front of its output layer; params = W, b pairs: [merge (W_R, None)], resizer, flat, output layer."""
 
     @staticmethod
-    def forward(ctx, R_pt, X1_pt, T, spec, *params):
-        n_res, n_flat = spec
+    def forward(ctx, R_pt, X1_pt, T, spec, zb, *params):
+        n_mrz, n_res, n_flat = spec
         B, tiles = R_pt.shape[0], R_pt.shape[1]
         dev = R_pt.device
         Ws, bs = list(params[0::2]), list(params[1::2])
@@ -484,19 +485,22 @@ class _DecoderSideFn(torch.autograd.Function):
         n_out = W_out.shape[0]
         mid_W, mid_b = Ws[:-1], bs[:-1]
         F = mid_W[0].shape[0]
-        n_mid = n_res + n_flat
+        n_mid = n_mrz + n_res + n_flat
+        if n_mrz:
+            mid_b[0] = zb
         train = any(ctx.needs_input_grad)
         imgs = _weight_images(mid_W, (1, 2) if train else (1,), F)
         fw = imgs[0]
         R_pt, X1_pt = R_pt.contiguous(), X1_pt.contiguous()
         pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
-        prog = Program(B, tiles, per_task=False, width=F)
+        prog = Program(B, tiles, per_task=bool(n_mrz), width=F)
         acts, bits = [], []
         for i in range(n_mid):
-            o = dict(img=fw[i], w_ref=("shared", mid_W[i]), bias=mid_b[i].detach() if mid_b[i] is not None else None, relu=True)
+            o = dict(img=fw[i], w_ref=("shared", mid_W[i]), bias=mid_b[i].detach().contiguous() if mid_b[i] is not None else None,
+                     relu=True, bias_per_task=bool(n_mrz and i == 0))
             if i == 0:
                 o["in_pt"] = R_pt.detach()
-            if i == n_res - 1:
+            if i == n_mrz + n_res - 1:
                 o["addend"] = X1_pt.detach()
             if train:
                 o["store_out"], o["store_bits"] = pt(), _bits(B, tiles, dev)
@@ -519,10 +523,10 @@ class _DecoderSideFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        n_res, n_flat = ctx.spec
-        n_mid = n_res + n_flat
+        n_mrz, n_res, n_flat = ctx.spec
+        n_mid = n_mrz + n_res + n_flat
         if g is None:
-            return (None,) * (4 + 2 * (n_mid + 1))
+            return (None,) * (5 + 2 * (n_mid + 1))
         B, T, tiles, n_out, F = ctx.geom
         sv = list(ctx.saved_tensors)
         R_pt, acts, bits, bw, Wo = sv[0], sv[1:1 + n_mid], sv[1 + n_mid:1 + 2 * n_mid], sv[1 + 2 * n_mid:1 + 3 * n_mid], sv[-1]
@@ -531,7 +535,7 @@ class _DecoderSideFn(torch.autograd.Function):
         g4[:, :T, :n_out] = g
         pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
         tr = ctx.trace_ref
-        prog = Program(B, tiles, per_task=False, width=F)
+        prog = Program(B, tiles, per_task=bool(n_mrz), width=F)
         dz = [None] * n_mid
         dR = pt() if ctx.needs_input_grad[0] else None
         for i in range(n_mid - 1, -1, -1):
@@ -548,7 +552,7 @@ class _DecoderSideFn(torch.autograd.Function):
         ins = [R_pt, *acts[:-1]]
         for j in range(n_mid):
             dW = torch.empty((F, F), dtype=torch.float32, device=dev)
-            db = torch.empty((F,), dtype=torch.float32, device=dev) if ctx.has_b[j] else None
+            db = torch.empty((F,), dtype=torch.float32, device=dev) if (ctx.has_b[j] and not (n_mrz and j == 0)) else None
             jobs.append(dict(dZ=dz[j], A=ins[j], N=F, K=F, dW=dW, db=db))
             grads += [dW, db]
         dz_out = torch.zeros(CH.pt_shape(B, tiles * 32, 4), dtype=torch.float32, device=dev)
@@ -560,8 +564,10 @@ class _DecoderSideFn(torch.autograd.Function):
         CH.run_wgrad(jobs, B, tiles * 32, dev, tag="decoder weight gradients")
         if CH.TRACE is not None:
             CH.TRACE.append(("wgrad", jobs, B, tiles * 32, False))
-        dX1 = dz[n_res - 1] if ctx.needs_input_grad[1] else None  # (the merge adds x1 in front of its ReLU: its dZ is x1's gradient)
-        return (dR, dX1, None, None, *grads)
+        dX1 = dz[n_mrz + n_res - 1] if ctx.needs_input_grad[1] else None  # (the merge adds x1 in front of its ReLU: its dZ is x1's gradient)
+        # the per-task bias of the latent merge: the sum of its dZ over the task's points (padding points carry zeros)
+        d_zb = FN.sum_points_pt(dz[0], tiles * 32, F)[:, :F].contiguous() if (n_mrz and ctx.needs_input_grad[4]) else None
+        return (dR, dX1, None, None, d_zb, *grads)
 
 
 def decoder_side_usable(model, T: int) -> bool:
@@ -584,19 +590,21 @@ def decoder_side_usable(model, T: int) -> bool:
     if not (_square(rs.layers(), F) and _square([fm.to_hidden, *fm.linears], F) and fm.out.in_features == F
             and fm.out.out_features <= 4):
         return False
-    return len(rs.layers()) + len(fm.linears) + 1 <= L.NPF_X6_MAX_OPS
+    return len(rs.layers()) + len(fm.linears) + 2 <= L.NPF_X6_MAX_OPS
 
 
-def decoder_side(model, R_pt: torch.Tensor, X1_pt: torch.Tensor, T: int) -> torch.Tensor:
+def decoder_side(model, R_pt: torch.Tensor, X1_pt: torch.Tensor, T: int, zb: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The decoder's sufficient statistics [B, T, 2 dy] from the target representations and the encoded targets (PT32 tensors
-    [B, tiles, F/4, 32, 4]; ``decoder_side_usable``)."""
+    [B, tiles, F/4, 32, 4]; ``decoder_side_usable``).  ``zb`` [B, F]: AttnLNP's merge_r_z in front, as in ``target_side``."""
     dec = model.decoder
     fm, rs = dec.flat_module, dec.resizer
     lins = [*rs.layers(), fm.to_hidden, *fm.linears, fm.out]
     params = []
     for lin in lins:
         params += [lin.weight, lin.bias]
-    return _DecoderSideFn.apply(R_pt, X1_pt, T, (len(rs.layers()), len(fm.linears) + 1), *params)
+    if zb is not None:
+        params[0:0] = [model.r_z_merger.weight[:, :model.r_dim], None]
+    return _DecoderSideFn.apply(R_pt, X1_pt, T, (int(zb is not None), len(rs.layers()), len(fm.linears) + 1), zb, *params)
 
 
 class _PairLinearFn(torch.autograd.Function):

@@ -381,3 +381,49 @@ def test_mlp_pt_matches_float64(B, T, L, r):
     assert_close(xd.grad, xr.grad, tol=1e-4, what="dx")
     for k, p in mlp.named_parameters():
         assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("B,T,L", [(3, 64, 2), (2, 70, 1)])
+def test_decoder_side_with_latent_merge_matches_float64(B, T, L):
+    """x6.decoder_side with AttnLNP's merge_r_z in front (base.py:554-575 as relu(W_R R + zb[task]), the latent half a per-task
+    bias): rows, dR, dX1, d zb and every dW / db against float64."""
+    import npf_gwwaveform_amd as A
+    from npf_gwwaveform_amd import functional as FN
+    from npf_gwwaveform_amd import x6
+
+    r = 128
+    torch.manual_seed(T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = A.AttnLNP(1, 2, attention="transformer", r_dim=r,
+                          Decoder=A.merge_flat_input(partial(A.MLP, n_hidden_layers=L, hidden_size=r), is_sum_merge=True)).to(DEV)
+    assert x6.decoder_side_usable(model, T)
+    g = torch.Generator().manual_seed(T + 1)
+    R, X1, zb = torch.randn(B, T, r, generator=g) * 0.5, torch.randn(B, T, r, generator=g) * 0.5, torch.randn(B, r, generator=g) * 0.3
+    w = torch.randn(B, T, 4, generator=g)
+    Rd, Xd, zd = (t.to(DEV).requires_grad_(True) for t in (R, X1, zb))
+    rows = x6.decoder_side(model, FN.pack_pt(Rd), FN.pack_pt(Xd), T, zb=zd)
+    (rows * w.to(DEV)).sum().backward()
+    d = lambda t: t.detach().double().cpu()  # noqa: E731
+    P = {k: d(v).requires_grad_(True) for k, v in model.named_parameters()}
+    lin = lambda x, pre: torch.nn.functional.linear(x, P[pre + ".weight"], P[pre + ".bias"])  # noqa: E731
+
+    def mlp(x, pre, n_lin):
+        h = torch.relu(lin(x, pre + ".to_hidden"))
+        for i in range(n_lin):
+            h = torch.relu(lin(h, f"{pre}.linears.{i}"))
+        return lin(h, pre + ".out")
+
+    Rr, Xr, zr = R.double().requires_grad_(True), X1.double().requires_grad_(True), zb.double().requires_grad_(True)
+    Rm = torch.relu(Rr @ P["r_z_merger.weight"][:, :r].t() + zr[:, None, :])
+    ref = mlp(torch.relu(Xr + mlp(Rm, "decoder.resizer", len(model.decoder.resizer.linears))), "decoder.flat_module",
+              len(model.decoder.flat_module.linears))
+    (ref * w.double()).sum().backward()
+    assert_close(rows, ref, tol=1e-5, what="rows")
+    assert_close(Rd.grad, Rr.grad, tol=1e-4, what="dR")
+    assert_close(Xd.grad, Xr.grad, tol=1e-4, what="dX1")
+    assert_close(zd.grad, zr.grad, tol=1e-4, what="d zb")
+    assert_close(model.r_z_merger.weight.grad[:, :r], P["r_z_merger.weight"].grad[:, :r], tol=1e-4, what="dW_R")
+    for k, p in model.named_parameters():
+        if k.startswith("decoder"):
+            assert_close(p.grad, P[k].grad, tol=1e-4, what=f"grad {k}")
