@@ -237,8 +237,9 @@ class _MhaFn(torch.autograd.Function):
         F = n_heads * MHA_HEAD
         q_pt, k_pt, v_pt = q_pt.contiguous(), k_pt.contiguous(), v_pt.contiguous()
         train = any(ctx.needs_input_grad[:3])
-        # (zeros: the features of a padded tile beyond F and the points beyond n_queries are not written by the kernel)
-        out = torch.zeros(CH.pt_shape(n_tasks, n_queries, F), dtype=torch.float32, device=q_pt.device)
+        # (zeros where the kernel leaves something unwritten: the features of a padded tile beyond F, the points beyond n_queries)
+        whole = F % 32 == 0 and n_queries % 32 == 0
+        out = (torch.empty if whole else torch.zeros)(CH.pt_shape(n_tasks, n_queries, F), dtype=torch.float32, device=q_pt.device)
         lse = torch.empty((n_tasks, n_heads, n_queries), dtype=torch.float32, device=q_pt.device) if train else None
         if CH.PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -261,7 +262,9 @@ class _MhaFn(torch.autograd.Function):
         n_tasks, n_keys, n_queries, n_heads, F = ctx.geom
         q_pt, k_pt, v_pt, out, lse = ctx.saved_tensors
         g = g.contiguous()
-        dq, dk, dv = torch.zeros_like(q_pt), torch.zeros_like(k_pt), torch.zeros_like(v_pt)
+        # (zeros where the kernel leaves something unwritten, as in the forward pass)
+        mk = lambda t, n: (torch.empty_like if (F % 32 == 0 and n % 32 == 0) else torch.zeros_like)(t)  # noqa: E731
+        dq, dk, dv = mk(q_pt, n_queries), mk(k_pt, n_keys), mk(v_pt, n_keys)
         if CH.PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()

@@ -531,8 +531,11 @@ class _DecoderSideFn(torch.autograd.Function):
         sv = list(ctx.saved_tensors)
         R_pt, acts, bits, bw, Wo = sv[0], sv[1:1 + n_mid], sv[1 + n_mid:1 + 2 * n_mid], sv[1 + 2 * n_mid:1 + 3 * n_mid], sv[-1]
         dev = g.device
-        g4 = torch.zeros((B, tiles * 32, 4), dtype=torch.float32, device=dev)  # (padding points and outputs: zero gradient)
-        g4[:, :T, :n_out] = g
+        if T == tiles * 32 and n_out == 4:
+            g4 = g.contiguous()
+        else:
+            g4 = torch.zeros((B, tiles * 32, 4), dtype=torch.float32, device=dev)  # (padding points and outputs: zero gradient)
+            g4[:, :T, :n_out] = g
         pt = lambda: CH.pt_empty(B, tiles * 32, F, dev)  # noqa: E731
         tr = ctx.trace_ref
         prog = Program(B, tiles, per_task=bool(n_mrz), width=F)
