@@ -206,20 +206,38 @@ def _bits(n_tasks, tiles, dev):
     return torch.empty((n_tasks, tiles, 2, 64), dtype=torch.int64, device=dev)
 
 
+_ZEROS = {}
+
+
+def _zeros(shape, device) -> torch.Tensor:
+    """A cached block of zeros (read-only: it only ever enters ``torch.cat``) -- padding by one copy launch instead of a fill and a
+    copy per call."""
+    key = (tuple(shape), str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = torch.zeros(shape, dtype=torch.float32, device=device)
+        if not (z.is_cuda and torch.cuda.is_current_stream_capturing()):  # (a block born inside a graph capture belongs to that graph)
+            _ZEROS[key] = z
+    return z
+
+
 def _pad_rows4(X: torch.Tensor) -> torch.Tensor:
     """[B, P, d] (d <= 4) -> contiguous [B, P, 4], zero padded."""
     d = X.shape[-1]
     if d == 4:
         return X.contiguous()
-    return torch.nn.functional.pad(X, (0, 4 - d)).contiguous()
+    return torch.cat((X, _zeros((*X.shape[:-1], 4 - d), X.device)), dim=-1)
 
 
 def _first_layer_matrix(W: torch.Tensor, n_out: int) -> torch.Tensor:
     """nn.Linear weight [n, d] (d <= 4) -> the rows-prologue matrix [4, n_out] = W^T, zero padded."""
     n, d = W.shape
-    out = torch.zeros((4, n_out), dtype=torch.float32, device=W.device)
-    out[:d, :n] = W.detach().t()
-    return out
+    Wt = W.detach().t()
+    if n < n_out:
+        Wt = torch.cat((Wt, _zeros((d, n_out - n), W.device)), dim=1)
+    if d < 4:
+        Wt = torch.cat((Wt, _zeros((4 - d, n_out), W.device)), dim=0)
+    return Wt.contiguous()
 
 
 def decode_rows_usable(mod, x1: torch.Tensor, x2: torch.Tensor) -> bool:
