@@ -263,11 +263,11 @@ int npf_split_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int
 int npf_merge_heads(const float *src, int32_t n_tasks, int32_t pts_per_task, int32_t F, int32_t n_heads, float *dst,
                     void *stream);
 
-/* Multihead scaled-dot attention with 16-feature heads, straight on the PT32 tensors of the K / Q / V projections
+/* Multihead scaled-dot attention with 16- or 32-feature heads (D = F / n_heads), straight on the PT32 tensors of the K / Q / V projections
  * (MultiheadAttender.forward between the projections and the concatenation, npf/architectures/attention.py:505-527 with
- * DotAttender :204-220 per head, scale 1 / sqrt(head size)): out(b, q, 16 h + :) = softmax_k(Q_h K_h^T / 4) V_h, X_h = features
- * 16 h .. 16 h + 15.  q / out: PT32 [n_tasks][n_queries][F], k / v: PT32 [n_tasks][n_keys][F], F = 16 n_heads (tiles of
- * roundup(F, 32) features), n_keys <= 256.  lse [n_tasks][n_heads][n_queries] (or NULL at inference): log-sum-exp of the scaled
+ * DotAttender :204-220 per head, scale 1 / sqrt(head size)): out(b, q, D h + :) = softmax_k(Q_h K_h^T / sqrt(D)) V_h, X_h = features
+ * D h .. D h + D - 1.  q / out: PT32 [n_tasks][n_queries][F], k / v: PT32 [n_tasks][n_keys][F], F = D n_heads (tiles of
+ * roundup(F, 32) features), n_keys <= 256 (D = 16) or 128 (D = 32).  lse [n_tasks][n_heads][n_queries] (or NULL at inference): log-sum-exp of the scaled
  * scores, what the backward pass recomputes the probabilities from.  fp32 MFMA, softmax with max subtraction.
  * npf_mha_bwd: d_q / d_k / d_v (PT32, same shapes as q / k / v; points and features outside the valid ranges are not written). */
 int npf_mha_fwd(const float *q, const float *k, const float *v, int32_t n_tasks, int32_t n_heads, int32_t n_keys,

@@ -496,8 +496,8 @@ class MultiheadAttender(nn.Module):
         projection when the launch that encoded the queries already made it (x6.xenc_proj)."""
         H, d = self.n_heads, self.kq_size
         if FN.mha_usable(self.kq_head_size, self.value_head_size, C):
-            # 16-feature heads (the reference's default r_dim = 128, 8 heads): one launch on the projected tensors, the heads are
-            # 16-feature slices of the PT32 tiles (csrc/mha_kernel.hip)
+            # 16- / 32-feature heads (the reference's default r_dim = 128 with 8 heads; 256 with 8): one launch on the projected
+            # tensors, the heads are feature slices of the PT32 tiles (csrc/mha_kernel.hip)
             from . import x6
 
             if x6.pair_linear_usable(self.key_transform, self.value_transform):  # (both on the context points: one launch)
@@ -505,7 +505,7 @@ class MultiheadAttender(nn.Module):
             else:
                 Kp, Vp = self._project(keys_pt, B, C, self.key_transform), self._project(values_pt, B, C, self.value_transform)
             Qp = queries_proj if queries_proj is not None else self._project(queries_pt, B, T, self.query_transform)
-            return FN.mha(Qp, Kp, Vp, B, C, T, H)
+            return FN.mha(Qp, Kp, Vp, B, C, T, H, self.kq_head_size)
         Kh = FN.split_heads(self._project(keys_pt, B, C, self.key_transform), B, C, d, H)
         Qh = FN.split_heads(self._project(queries_pt, B, T, self.query_transform), B, T, d, H)
         Vh = FN.split_heads(self._project(values_pt, B, C, self.value_transform), B, C, self.value_size, H)

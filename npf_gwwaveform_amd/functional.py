@@ -221,20 +221,19 @@ def merge_heads(x_pt: torch.Tensor, n_tasks: int, pts: int, F: int, n_heads: int
     return _HeadsFn.apply(x_pt, n_tasks, pts, F, n_heads, False)
 
 
-MHA_HEAD = 16      # head size of the fused multihead attention kernel (csrc/mha_kernel.hip)
-MHA_MAX_KEYS = 256
+MHA_MAX_KEYS = {16: 256, 32: 128}  # head size -> keys the fused multihead attention kernel takes (csrc/mha_kernel.hip)
 MHA_ENABLED = os.environ.get("NPF_NO_MHA", "0") != "1"  # NPF_NO_MHA=1: heads as extra tasks on the chain kernel (round 2)
 
 
 class _MhaFn(torch.autograd.Function):
-    """out[b, q, 16 h + :] = softmax_k(Q_h K_h^T / 4) V_h on the PT32 tensors of the K / Q / V projections (``npf_mha_fwd`` /
+    """out[b, q, D h + :] = softmax_k(Q_h K_h^T / sqrt(D)) V_h on the PT32 tensors of the K / Q / V projections (``npf_mha_fwd`` /
     ``npf_mha_bwd``; MultiheadAttender.forward, npf/architectures/attention.py:505-527 with DotAttender :204-220 per head)."""
 
     @staticmethod
-    def forward(ctx, q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads):
+    def forward(ctx, q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads, head):
         from . import chain as CH
 
-        F = n_heads * MHA_HEAD
+        F = n_heads * head
         q_pt, k_pt, v_pt = q_pt.contiguous(), k_pt.contiguous(), v_pt.contiguous()
         train = any(ctx.needs_input_grad[:3])
         # (zeros where the kernel leaves something unwritten: the features of a padded tile beyond F, the points beyond n_queries)
@@ -274,22 +273,23 @@ class _MhaFn(torch.autograd.Function):
             ev1.record()
             CH.PROFILE.append(("mha_bwd_kernel", 14 * n_tasks * n_queries * n_keys * F, ev0, ev1,
                                4 * F * n_tasks * (4 * n_queries + 4 * n_keys), "multihead attention backward"))
-        return dq, dk, dv, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
 def mha_usable(kq_head: int, v_head: int, n_keys: int) -> bool:
-    """Does the fused multihead attention kernel take this: fp32 mode, 16-feature heads, at most 256 keys."""
+    """Does the fused multihead attention kernel take this: fp32 mode, 16-feature heads and at most 256 keys, or 32-feature heads
+    and at most 128."""
     from . import chain as CH
 
-    return (MHA_ENABLED and CH.COMPUTE_DTYPE == "fp32" and kq_head == MHA_HEAD and v_head == MHA_HEAD
-            and 0 < n_keys <= MHA_MAX_KEYS)
+    return (MHA_ENABLED and CH.COMPUTE_DTYPE == "fp32" and kq_head == v_head and kq_head in MHA_MAX_KEYS
+            and 0 < n_keys <= MHA_MAX_KEYS[kq_head])
 
 
 def mha(q_pt: torch.Tensor, k_pt: torch.Tensor, v_pt: torch.Tensor, n_tasks: int, n_keys: int, n_queries: int,
-        n_heads: int) -> torch.Tensor:
-    """PT32 [n_tasks, n_queries, 16 n_heads]: per-head scaled-dot attention of the projected queries over the projected keys /
+        n_heads: int, head: int = 16) -> torch.Tensor:
+    """PT32 [n_tasks, n_queries, head * n_heads]: per-head scaled-dot attention of the projected queries over the projected keys /
     values (``mha_usable``), no split / merge of heads in memory."""
-    return _MhaFn.apply(q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads)
+    return _MhaFn.apply(q_pt, k_pt, v_pt, n_tasks, n_keys, n_queries, n_heads, head)
 
 
 class _AddLayerNormFn(torch.autograd.Function):

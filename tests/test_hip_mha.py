@@ -21,18 +21,19 @@ def _ref(Q, K, V, H):
     return (S.softmax(-1) @ heads(V)).permute(0, 2, 1, 3).reshape(B, T, F)
 
 
-@pytest.mark.parametrize("B,C,T,H", [(3, 128, 256, 8), (2, 37, 70, 2), (2, 200, 33, 8), (1, 256, 100, 4), (2, 5, 1, 1), (4, 50, 128, 8),
-                                     (2, 64, 257, 3)])
-def test_mha_matches_float64(B, C, T, H):
+@pytest.mark.parametrize("B,C,T,H,D", [(3, 128, 256, 8, 16), (2, 37, 70, 2, 16), (2, 200, 33, 8, 16), (1, 256, 100, 4, 16), (2, 5, 1, 1, 16),
+                                       (4, 50, 128, 8, 16), (2, 64, 257, 3, 16),
+                                       (2, 128, 96, 8, 32), (3, 37, 70, 2, 32), (2, 100, 33, 1, 32), (1, 64, 257, 3, 32)])
+def test_mha_matches_float64(B, C, T, H, D):
     from npf_gwwaveform_amd import functional as FN
 
-    F = 16 * H
-    assert FN.mha_usable(16, 16, C)
+    F = D * H
+    assert FN.mha_usable(D, D, C)
     g = torch.Generator().manual_seed(B * 1000 + C + T)
     Q, K, V = (torch.randn(B, n, F, generator=g) * s for n, s in ((T, 1.5), (C, 1.5), (C, 1.0)))
     w = torch.randn(B, T, F, generator=g)
     Qd, Kd, Vd = (x.to(DEV).requires_grad_(True) for x in (Q, K, V))
-    out = FN.unpack_pt(FN.mha(FN.pack_pt(Qd), FN.pack_pt(Kd), FN.pack_pt(Vd), B, C, T, H), T, F)
+    out = FN.unpack_pt(FN.mha(FN.pack_pt(Qd), FN.pack_pt(Kd), FN.pack_pt(Vd), B, C, T, H, D), T, F)
     (out * w.to(DEV)).sum().backward()
     Qr, Kr, Vr = (x.double().requires_grad_(True) for x in (Q, K, V))
     ref = _ref(Qr, Kr, Vr, H)
@@ -60,7 +61,8 @@ def test_mha_rejects_other_head_sizes_and_too_many_keys():
 
     x = CH.pt_empty(1, 32, 128, DEV)
     lib = L.load()
-    assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 4, 32, 32, 128, L.ptr(x), None, None) == -1   # 128 != 16 * 4
+    assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 2, 32, 32, 128, L.ptr(x), None, None) == -1   # 64-feature heads
+    assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 4, 129, 32, 128, L.ptr(x), None, None) == -1  # 32-feature heads: <= 128 keys
     assert lib.npf_mha_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 1, 8, 257, 32, 128, L.ptr(x), None, None) == -1  # keys > 256
 
 
